@@ -1,0 +1,135 @@
+"""Platform-exact synthetic weights and inputs.
+
+The reference ships no checkpoints usable offline and its 185 M parameters cannot be
+committed as fixtures (hard part 6), so both the golden-vector generator
+(tools/gen_golden.py, runs the imported reference) and the GPU parity tests rebuild the
+same tensors from (name, shape, seed) with integer hashing only: splitmix64 counters ->
+24-bit uniforms -> IEEE float64 arithmetic -> float32.  No libm transcendental is
+involved, so the bits are identical on any machine.
+
+Per-tensor scales follow the reference's initialisers where it has them
+(VitaCLIP_vision_encoder.py:62-84, VitaCLIP_vision_encoder_utils.py:54-57,144-152,
+VitaCLIP_text_encoder.py:238) and the CLIP convention where the reference leaves
+``torch.empty`` (VitaCLIP_text_encoder.py:141,143).  Biases and LayerNorm affines are
+deliberately non-trivial so that a dropped bias/affine shows up in parity.
+"""
+import math
+import numpy as np
+
+from .config import VitaConfig, param_shapes
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _fnv1a64(s: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in s.encode("utf-8"):
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _splitmix64(z: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = z + _GOLD
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _uniform01(key: int, n: int, stream: int = 0, chunk: int = 1 << 24) -> np.ndarray:
+    """n float64 values in (0,1), 24-bit resolution, from counter-mode splitmix64."""
+    out = np.empty(n, dtype=np.float64)
+    base = np.uint64((key + stream * 0xD1342543DE82EF95) & 0xFFFFFFFFFFFFFFFF)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        ctr = np.arange(s, e, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            z = _splitmix64(base + ctr * _GOLD)
+        out[s:e] = ((z >> np.uint64(40)).astype(np.float64) + 0.5) * (1.0 / 16777216.0)
+    return out
+
+
+def uniform_pm1(name: str, shape, seed: int = 0) -> np.ndarray:
+    """float64 uniform in (-1, 1)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    key = _fnv1a64(name) ^ ((seed * 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF)
+    return (2.0 * _uniform01(key, n) - 1.0).reshape(shape)
+
+
+def normalish(name: str, shape, seed: int = 0) -> np.ndarray:
+    """float64, zero mean, unit variance, bell-shaped (Irwin-Hall of 4 uniforms)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    key = _fnv1a64(name) ^ ((seed * 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF)
+    acc = np.zeros(n, dtype=np.float64)
+    for k in range(4):
+        acc += _uniform01(key, n, stream=k + 1)
+    return ((acc - 2.0) * math.sqrt(3.0)).reshape(shape)
+
+
+def _rule(name: str, shape, cfg: VitaConfig):
+    """-> (kind, scale, offset) with kind in {'u','n','const'}."""
+    D, W, P = cfg.feature_dim, cfg.text_width, cfg.patch_size
+    if name == "logit_scale":
+        return "const", 0.0, math.log(1.0 / 0.07)
+    leaf = name.rsplit(".", 1)[-1]
+    is_ln = any(t in name for t in ("ln_pre", "ln_post", "norm1", "norm2", "summary_ln",
+                                    "ln_1", "ln_2", "ln_final"))
+    if is_ln:
+        return ("u", 0.1, 1.0) if leaf == "weight" else ("u", 0.05, 0.0)
+    if leaf in ("bias", "in_proj_bias"):
+        return "u", 0.02, 0.0
+    if name in ("visual.cls_token", "visual.pos_embed", "visual.time_embed"):
+        return "n", 0.02, 0.0
+    if name == "visual.proj":
+        return "n", D ** -0.5, 0.0
+    if name == "visual.global_prompts" or leaf == "local_prompts":
+        return "u", math.sqrt(6.0 / (3 * P * P + D)), 0.0
+    if name == "visual.patch_embed.proj.weight":
+        return "u", 1.0 / math.sqrt(3 * P * P), 0.0
+    if name.startswith("visual.blocks.") and leaf == "weight":
+        fan_out, fan_in = shape
+        if "cls_proj" in name:
+            return "u", 1.0 / math.sqrt(fan_in), 0.0
+        return "u", math.sqrt(6.0 / (fan_in + fan_out)), 0.0
+    if name == "textual.positional_embedding":
+        return "n", 0.01, 0.0
+    if name == "textual.text_projection":
+        return "n", W ** -0.5, 0.0
+    if name == "textual.token_embedding.weight":
+        return "n", 0.02, 0.0
+    if name.startswith("textual.transformer.resblocks."):
+        L = cfg.text_layers
+        if leaf == "in_proj_weight":
+            return "n", W ** -0.5, 0.0
+        if "out_proj" in name or "c_proj" in name:
+            return "n", (W ** -0.5) * ((2 * L) ** -0.5), 0.0
+        if "c_fc" in name:
+            return "n", (2 * W) ** -0.5, 0.0
+    if name == "prompt_learner.ctx":
+        return "n", 0.02, 0.0
+    raise KeyError(f"no synth rule for {name}")
+
+
+def synth_param(name: str, shape, cfg: VitaConfig, seed: int = 0) -> np.ndarray:
+    kind, scale, offset = _rule(name, shape, cfg)
+    if kind == "const":
+        return np.full(shape, offset, dtype=np.float32)
+    base = uniform_pm1(name, shape, seed) if kind == "u" else normalish(name, shape, seed)
+    return (base * scale + offset).astype(np.float32)
+
+
+def synth_state_dict(cfg: VitaConfig, n_cls: int, seed: int = 0):
+    """OrderedDict name -> float32 ndarray for every key of the reference state_dict."""
+    from collections import OrderedDict
+    out = OrderedDict()
+    for name, shape in param_shapes(cfg, n_cls).items():
+        out[name] = synth_param(name, shape, cfg, seed)
+    return out
+
+
+def synth_clip(B: int, T: int, size: int, seed: int = 1234) -> np.ndarray:
+    """(B,3,T,size,size) float32, ~N(0,1): the post-normalisation frame statistics of
+    /root/reference/video_dataset/dataset.py:117-139."""
+    return normalish("input.clip", (B, 3, T, size, size), seed).astype(np.float32)

@@ -1,0 +1,135 @@
+#!/usr/bin/env python
+"""Generate tests/golden/* by running the REFERENCE implementation in the build container.
+
+Runs only where /root/reference exists (never on the GPU box).  The reference is imported
+read-only with two module shims: ``ftfy`` (identity on the ASCII class
+lists) and ``video_dataset`` (only the constant NUM_COMB=70,
+/root/reference/video_dataset/dataset.py:19).  Weights and inputs come from
+gava_clip_amd/synth.py and are loaded with ``strict=True`` (which also pins state_dict key
+parity).  Outputs are data only: logits, features, per-layer CLS rows, token ids.
+
+    python tools/gen_golden.py            # writes tests/golden/{c1_b16,tiny}.npz, tokens_*.json
+"""
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+from gava_clip_amd.config import VIT_B16_T8, TINY, param_shapes  # noqa: E402
+from gava_clip_amd import synth  # noqa: E402
+
+CLASSES = os.path.join(REPO, "gava_clip_amd", "data", "classes")
+
+
+def import_reference():
+    ftfy = types.ModuleType("ftfy")
+    ftfy.fix_text = lambda s: s
+    sys.modules["ftfy"] = ftfy
+    vd = types.ModuleType("video_dataset")
+    vd.NUM_COMB = 70
+    sys.modules["video_dataset"] = vd
+    sys.path.insert(0, os.path.join(REF, "training"))
+    import VitaCLIP_model  # noqa
+    import VitaCLIP_text_encoder  # noqa
+    return VitaCLIP_model, VitaCLIP_text_encoder
+
+
+def build_reference(mod, cfg, class_file):
+    model = mod.VitaCLIP(
+        backbone_path="", input_size=(cfg.input_size, cfg.input_size), num_frames=cfg.num_frames,
+        feature_dim=cfg.feature_dim, patch_size=(cfg.patch_size, cfg.patch_size),
+        num_heads=cfg.num_heads, num_layers=cfg.num_layers, mlp_factor=cfg.mlp_factor,
+        embed_dim=cfg.embed_dim, use_summary_token=True, use_local_prompts=True,
+        use_global_prompts=True, num_global_prompts=cfg.num_global_prompts,
+        use_text_prompt_learning=True, text_context_length=cfg.text_context_length,
+        text_vocab_size=cfg.text_vocab_size, text_transformer_width=cfg.text_width,
+        text_transformer_heads=cfg.text_heads, text_transformer_layers=cfg.text_layers,
+        text_num_prompts=cfg.text_num_prompts, text_prompt_pos="end", text_prompt_init="",
+        text_prompt_CSC=True, text_prompt_classes_path=class_file)
+    return model
+
+
+def load_synth(model, cfg, n_cls, seed=0):
+    sd = synth.synth_state_dict(cfg, n_cls, seed)
+    ref_keys = list(model.state_dict().keys())
+    assert ref_keys == list(sd.keys()), "state_dict key order/name mismatch with reference"
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    # TextPromptLearner caches token embeddings at construction (text_encoder.py:284,296-300):
+    # rebuild them from the loaded embedding table exactly as its __init__ does.
+    pl = model.prompt_learner
+    with torch.no_grad():
+        for idc in range(pl.n_cls):
+            emb = model.textual.token_embedding(pl.tokenized_prompts[idc])
+            pl.token_prefix[idc] = emb[:, :1, :]
+            pl.token_suffix[idc] = emb[:, 1 + pl.n_ctx:, :]
+    return sd
+
+
+def run_case(mod, cfg, class_file, B, name, full_trace):
+    from gava_clip_amd.tokenizer import read_class_names
+    n_cls = len(read_class_names(class_file))
+    model = build_reference(mod, cfg, class_file)
+    load_synth(model, cfg, n_cls)
+    model.eval()
+    x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size, seed=1234))
+    blocks_out = []
+    hooks = [blk.register_forward_hook(lambda m, i, o: blocks_out.append((o[0].detach(), o[1].detach())))
+             for blk in model.visual.blocks]
+    vis_out = []
+    hooks.append(model.visual.register_forward_hook(lambda m, i, o: vis_out.append(o)))
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        logits, lmt, lvm = model(x)
+    assert lmt is None and lvm is None
+    for h in hooks:
+        h.remove()
+    cls_x, summary = vis_out[0]
+    vf = cls_x / cls_x.norm(dim=-1, keepdim=True)
+    G = cfg.num_global_prompts
+    out = dict(
+        logits=logits.numpy(), scores=logits.softmax(-1).numpy(), video_features=vf.numpy(),
+        text_features=model.text_features.numpy(), summary=summary.numpy(),
+        cls_rows=np.stack([b[0][:, 0, :].numpy() for b in blocks_out]),
+        patch_row7=np.stack([b[0][:, G + 1 + 7, :].numpy() for b in blocks_out]),
+        block_fro=np.array([float(torch.cat((b[0][:, :1], b[0][:, G + 1:]), 1).norm()) for b in blocks_out]),
+        summ_last=blocks_out[-1][1].numpy(),
+        x_checksum=np.array([float(x.double().sum()), float(x.double().abs().sum())]),
+        tokens=torch.cat(model.tokenized_prompts).numpy().astype(np.int32),
+    )
+    if full_trace:
+        for i, b in enumerate(blocks_out):
+            out[f"block{i}"] = torch.cat((b[0][:, :1], b[0][:, G + 1:]), 1).numpy()
+            out[f"summ{i}"] = b[1].numpy()
+    path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
+    print("wrote", path, {k: np.asarray(v).shape for k, v in out.items() if not k.startswith("block")})
+    return out
+
+
+def dump_tokens(txt_mod):
+    from gava_clip_amd.tokenizer import read_class_names, prompt_texts
+    for fn in ("updrs_3cls_classes.txt", "k400_classes.txt"):
+        names = read_class_names(os.path.join(CLASSES, fn))
+        texts = prompt_texts(names, 8)
+        ids = torch.cat([txt_mod.tokenize(t) for t in texts]).numpy().astype(int).tolist()
+        path = os.path.join(REPO, "tests", "golden", "tokens_" + fn.replace("_classes.txt", "") + ".json")
+        with open(path, "w") as f:
+            json.dump({"texts": texts, "ids": ids}, f)
+        print("wrote", path, len(ids))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    mod, txt_mod = import_reference()
+    dump_tokens(txt_mod)
+    run_case(mod, TINY, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "tiny", True)
+    run_case(mod, VIT_B16_T8, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "c1_b16", False)
