@@ -1,0 +1,181 @@
+// attention.hip — fused softmax(Q K^T) V, head dim 64, 16-bit MFMA operands, fp32 softmax.
+//
+// gfx950 design: one workgroup (4 waves) per (problem, head).  The whole key set of a problem is
+// short (<= 320 keys: 214 for ViT-B/16 with T=8), so K and V of one head are staged ONCE in LDS
+// (160-byte padded rows: conflict-free for both the ds_read_b128 K-fragment reads and the
+// ds_read_b64_tr_b16 transposed V reads) and softmax is single pass: no online rescaling.
+// Per 16-query tile a wave computes S^T = K Q^T with the KEY on the MFMA row, so every lane
+// holds, for its own query (lane&15), 4 consecutive keys per 16-key tile.  That accumulator
+// layout is already the B-operand layout of the second product O^T = V^T P^T (k-slot order
+// permuted identically on both operands), so P never leaves registers; V^T fragments come from
+// the hardware-transposing LDS read.  O^T leaves each lane with 4 consecutive head-dim columns
+// of its own query: 8-byte stores, row sum in-lane.
+// Vision "side" keys (global/local prompts, summary token) are gathered from a separate small
+// K/V matrix while staging, so prompt tokens are never materialised per frame.
+#include "common.h"
+
+namespace {
+
+constexpr int LDS_ROW = 160;  // bytes per K/V row in LDS (64 x 2 B + 32 B pad)
+
+struct AttnParams {
+  const unsigned short* q; const unsigned short* k; const unsigned short* v; long ld;
+  const unsigned short* sk; const unsigned short* sv; long lds;
+  unsigned short* out; long ldo;
+  int batch, heads, n_q, n_kmain, n_g, T, has_summary, n_keys, causal;
+};
+
+template <class P, int NKT>
+__global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+  constexpr int KP = NKT * 16;
+  __shared__ __attribute__((aligned(16))) char smem[2 * KP * LDS_ROW];
+  char* Ks = smem;
+  char* Vs = smem + KP * LDS_ROW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.x / p.heads, h = blockIdx.x - n * p.heads;
+
+  // ---- stage K, V (16 B per lane-task; rows beyond n_keys are zero so that 0 * V stays finite)
+  for (int id = tid; id < KP * 8; id += 256) {
+    const int row = id >> 3, chunk = id & 7;
+    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+    if (row < p.n_keys) {
+      const unsigned short *kr, *vr;
+      if (row < p.n_kmain) {
+        const long off = ((long)n * p.n_kmain + row) * p.ld + h * 64 + chunk * 8;
+        kr = p.k + off; vr = p.v + off;
+      } else {
+        const int s = row - p.n_kmain;
+        long sr;
+        if (s < p.n_g) sr = s;
+        else if (s < p.n_g + p.T) sr = p.n_g + (long)(n / p.T) * p.T + (s - p.n_g);
+        else sr = p.n_g + p.batch + n;
+        const long off = sr * p.lds + h * 64 + chunk * 8;
+        kr = p.sk + off; vr = p.sv + off;
+      }
+      kv = *reinterpret_cast<const uint4*>(kr);
+      vv = *reinterpret_cast<const uint4*>(vr);
+    }
+    *reinterpret_cast<uint4*>(Ks + row * LDS_ROW + chunk * 16) = kv;
+    *reinterpret_cast<uint4*>(Vs + row * LDS_ROW + chunk * 16) = vv;
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n_qt = (p.n_q + 15) >> 4;
+  // transposed-read lane address: lane 4q+pp of a 16-lane group supplies row q, columns 4pp..4pp+3
+  const int tr_off = (4 * fg + (fr >> 2)) * LDS_ROW + (fr & 3) * 8;
+
+  for (int qt = wave; qt < n_qt; qt += 4) {
+    const int qi = qt * 16 + fr;
+    const int qrow = qi < p.n_q ? qi : p.n_q - 1;
+    const unsigned short* qp = p.q + ((long)n * p.n_q + qrow) * p.ld + h * 64 + 8 * fg;
+    const s16x8_t q0 = *reinterpret_cast<const s16x8_t*>(qp);
+    const s16x8_t q1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
+
+    f32x4_t s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const char* kr = Ks + (kt * 16 + fr) * LDS_ROW + fg * 16;
+      const s16x8_t k0 = *reinterpret_cast<const s16x8_t*>(kr);
+      const s16x8_t k1 = *reinterpret_cast<const s16x8_t*>(kr + 64);
+      f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      a = P::mfma(k0, q0, a);
+      a = P::mfma(k1, q1, a);
+      s[kt] = a;
+    }
+    // mask + row max (keys of this query are spread over the 4 lanes sharing lane&15)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * fg + r;
+        const bool ok = key < p.n_keys && (!p.causal || key <= qi);
+        s[kt][r] = ok ? s[kt][r] : -INFINITY;
+        mx = fmaxf(mx, s[kt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[kt][r] - mx);
+        s[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NKT / 2; ++c) {
+      const uint2 lo = pack4<P>(s[2 * c][0], s[2 * c][1], s[2 * c][2], s[2 * c][3]);
+      const uint2 hi = pack4<P>(s[2 * c + 1][0], s[2 * c + 1][1], s[2 * c + 1][2], s[2 * c + 1][3]);
+      const s16x8_t pf = __builtin_bit_cast(s16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+      const char* vb = Vs + c * 32 * LDS_ROW + tr_off;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const s16x4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + dt * 32));
+        const s16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + 16 * LDS_ROW + dt * 32));
+        const s16x8_t vf = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+        o[dt] = P::mfma(vf, pf, o[dt]);
+      }
+    }
+    if (qi < p.n_q) {
+      unsigned short* op = p.out + ((long)n * p.n_q + qi) * p.ldo + h * 64 + 4 * fg;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<uint2*>(op + dt * 16) =
+            pack4<P>(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    }
+  }
+}
+
+template <class P>
+int launch_attn(const AttnParams& p, hipStream_t s) {
+  dim3 grid(p.batch * p.heads), block(256);
+  const int tiles = (p.n_keys + 15) / 16;
+  if (tiles <= 2) hipLaunchKernelGGL((attention_kernel<P, 2>), grid, block, 0, s, p);
+  else if (tiles <= 6) hipLaunchKernelGGL((attention_kernel<P, 6>), grid, block, 0, s, p);
+  else if (tiles <= 14) hipLaunchKernelGGL((attention_kernel<P, 14>), grid, block, 0, s, p);
+  else if (tiles <= 20) hipLaunchKernelGGL((attention_kernel<P, 20>), grid, block, 0, s, p);
+  else return GAVA_EINVAL;
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+}  // namespace
+
+extern "C" int gava_attention(const gava_attention_args* a, gava_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->v || !a->out) return GAVA_EINVAL;
+  if (a->batch <= 0 || a->heads <= 0 || a->n_q <= 0 || a->n_kmain <= 0) return GAVA_EINVAL;
+  if (a->ld_qkv % 8 || a->ld_out % 4) return GAVA_EINVAL;
+  if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) return GAVA_EINVAL;
+  if ((uintptr_t)a->out & 7) return GAVA_EINVAL;
+  int n_side = 0;
+  if (a->n_g || a->T || a->has_summary) {
+    if (!a->side_k || !a->side_v || a->ld_side % 8 || a->n_g < 0 || a->T <= 0) return GAVA_EINVAL;
+    if (((uintptr_t)a->side_k | (uintptr_t)a->side_v) & 15) return GAVA_EINVAL;
+    if (a->batch % a->T) return GAVA_EINVAL;
+    n_side = a->n_g + a->T + (a->has_summary ? 1 : 0);
+  }
+  AttnParams p;
+  p.q = (const unsigned short*)a->q; p.k = (const unsigned short*)a->k; p.v = (const unsigned short*)a->v;
+  p.ld = a->ld_qkv;
+  p.sk = (const unsigned short*)a->side_k; p.sv = (const unsigned short*)a->side_v; p.lds = a->ld_side;
+  p.out = (unsigned short*)a->out; p.ldo = a->ld_out;
+  p.batch = a->batch; p.heads = a->heads; p.n_q = a->n_q; p.n_kmain = a->n_kmain;
+  p.n_g = a->n_g; p.T = n_side ? a->T : 1; p.has_summary = a->has_summary;
+  p.n_keys = a->n_kmain + n_side; p.causal = a->causal;
+  if (p.n_keys > 320) return GAVA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->prec == GAVA_PREC_F16) return launch_attn<PrecF16>(p, s);
+  if (a->prec == GAVA_PREC_BF16) return launch_attn<PrecBF16>(p, s);
+  return GAVA_EINVAL;
+}

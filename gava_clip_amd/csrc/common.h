@@ -1,0 +1,66 @@
+// common.h — device-side building blocks shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gava_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// 16-bit MFMA operand precisions.  Storage is always 2 bytes; fragments travel as 8 x 16-bit.
+struct PrecF16 {
+  typedef _Float16 T;
+  static __device__ __forceinline__ f32x4_t mfma(s16x8_t a, s16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ unsigned short cvt(float x) {
+    return __builtin_bit_cast(unsigned short, (_Float16)x);
+  }
+  static __device__ __forceinline__ float up(unsigned short u) {
+    return (float)__builtin_bit_cast(_Float16, u);
+  }
+};
+struct PrecBF16 {
+  typedef __bf16 T;
+  static __device__ __forceinline__ f32x4_t mfma(s16x8_t a, s16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ unsigned short cvt(float x) {
+    return __builtin_bit_cast(unsigned short, (__bf16)x);
+  }
+  static __device__ __forceinline__ float up(unsigned short u) {
+    return __builtin_bit_cast(float, (unsigned)u << 16);
+  }
+};
+
+template <class P>
+static __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  uint2 r;
+  r.x = (unsigned)P::cvt(a) | ((unsigned)P::cvt(b) << 16);
+  r.y = (unsigned)P::cvt(c) | ((unsigned)P::cvt(d) << 16);
+  return r;
+}
+
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static __device__ __forceinline__ float quick_gelu(float x) {
+  // x * sigmoid(1.702 x)  (VitaCLIP_vision_encoder_utils.py:18-20)
+  return x / (1.0f + __expf(-1.702f * x));
+}
+
+#define GAVA_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    if (hipGetLastError() != hipSuccess) return GAVA_ELAUNCH; \
+  } while (0)

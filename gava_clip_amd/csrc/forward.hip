@@ -1,0 +1,233 @@
+// forward.hip — host-side drivers that chain the kernels into the vision / text forward passes.
+// Pure launch code: no allocation, no synchronisation, capturable into a hipGraph.
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+struct Carver {
+  char* base; size_t off, cap;
+  Carver(void* b, size_t c) : base((char*)b), off(0), cap(c) {}
+  void* take(size_t bytes) {
+    const size_t a = (off + 255) & ~(size_t)255;
+    off = a + bytes;
+    return base ? (void*)(base + a) : nullptr;
+  }
+};
+
+#define TRY(x)              \
+  do {                      \
+    const int _e = (x);     \
+    if (_e != GAVA_OK) return _e; \
+  } while (0)
+
+int ln(const float* in, long in_stride, const int32_t* idx, const float* g, const float* b, void* o16, long o16s,
+       float* o32, long o32s, int rows, int D, int prec, gava_stream_t s) {
+  gava_layernorm_args a{};
+  a.in = in; a.in_stride = in_stride; a.in_row_index = idx; a.gamma = g; a.beta = b;
+  a.out16 = o16; a.out16_stride = o16s; a.out32 = o32; a.out32_stride = o32s;
+  a.rows = rows; a.D = D; a.prec = prec;
+  return gava_layernorm(&a, s);
+}
+
+int gemm(const void* A, long lda, const void* W, long ldw, const float* bias, void* out, long ldo, int M, int N, int K,
+         int epi, int prec, gava_stream_t s, const float* resid = nullptr, long ldr = 0, int scale_cols = 0,
+         float scale = 1.f) {
+  gava_gemm_args a{};
+  a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo;
+  a.resid = resid; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.prec = prec;
+  a.scale_cols = scale_cols; a.scale = scale;
+  return gava_gemm(&a, s);
+}
+
+struct VisionWs {
+  float* X; void* Xn; void* QKV; void* MIX; void* HID; void* PATCH;
+  void* CLS16; float* CP; void* CPn; void* SQKV; void* SMIX; float* SUMM; void* SIDEn; void* SIDEKV;
+  void* CLSPOST; float* PROJ;
+  size_t total;
+};
+
+int patch_k(const gava_vision_model* m) { return (3 * m->P * m->P + 63) / 64 * 64; }
+
+VisionWs carve_vision(const gava_vision_model* m, void* ws, size_t cap) {
+  const long g = m->size / m->P, n = g * g, BT = (long)m->B * m->T_in, R = BT * (n + 1);
+  const long D = m->D, F = m->F, E = m->E, SR = m->G + 2 * BT;
+  Carver c(ws, cap);
+  VisionWs w;
+  w.X = (float*)c.take(R * D * 4);
+  w.Xn = c.take(R * D * 2);
+  w.QKV = c.take(R * 3 * D * 2);
+  w.MIX = c.take(R * D * 2);
+  const size_t hid = (size_t)R * F * 2, patch = (size_t)BT * n * patch_k(m) * 2;
+  w.HID = c.take(hid > patch ? hid : patch);
+  w.PATCH = w.HID;  // the patch matrix is dead before the first fc1
+  w.CLS16 = c.take(BT * D * 2);
+  w.CP = (float*)c.take(BT * D * 4);
+  w.CPn = c.take(BT * D * 2);
+  w.SQKV = c.take(BT * 3 * D * 2);
+  w.SMIX = c.take(BT * D * 2);
+  w.SUMM = (float*)c.take(BT * D * 4);
+  w.SIDEn = c.take(SR * D * 2);
+  w.SIDEKV = c.take(SR * 2 * D * 2);
+  w.CLSPOST = c.take(BT * D * 2);
+  w.PROJ = (float*)c.take(BT * E * 4);
+  w.total = (c.off + 255) & ~(size_t)255;
+  return w;
+}
+
+int check_vision(const gava_vision_model* m) {
+  if (!m || !m->layer) return GAVA_EINVAL;
+  if (m->B <= 0 || m->T_in <= 0 || m->T_model <= 0 || m->layers <= 0) return GAVA_EINVAL;
+  if (m->size % m->P || m->D != m->H * 64 || m->D % 128 || m->F % 128 || m->E % 128) return GAVA_EINVAL;
+  if (m->D > 1024) return GAVA_EINVAL;
+  if (((long)m->B * m->T_in) % m->T_model) return GAVA_EINVAL;  // reference: view(B,T,C) fails (utils:160-163)
+  const long g = m->size / m->P;
+  if (g * g + 1 + m->G + m->T_model + 1 > 320) return GAVA_EINVAL;
+  return GAVA_OK;
+}
+
+}  // namespace
+
+extern "C" int gava_abi_version(void) { return 1; }
+
+extern "C" size_t gava_vision_workspace_bytes(const gava_vision_model* m) {
+  if (check_vision(m) != GAVA_OK) return 0;
+  return carve_vision(m, nullptr, 0).total;
+}
+
+extern "C" int gava_vision_forward(const gava_vision_model* m, const float* x, float* cls_x, float* summary,
+                                   float* debug_cls, void* workspace, size_t workspace_bytes, gava_stream_t stream) {
+  TRY(check_vision(m));
+  if (!x || !cls_x || !summary || !workspace) return GAVA_EINVAL;
+  const VisionWs w = carve_vision(m, workspace, workspace_bytes);
+  if (w.total > workspace_bytes) return GAVA_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int g = m->size / m->P, n = g * g, BT = m->B * m->T_in, R = BT * (n + 1);
+  const int D = m->D, F = m->F, E = m->E, G = m->G, Tm = m->T_model, pr = m->prec;
+  const int Kp = patch_k(m), SR = G + 2 * BT;
+  const long fs = (long)(n + 1) * D;  // frame stride in X
+  const char* h16 = nullptr; (void)h16;
+
+  // ---- embedding (VitaCLIP_vision_encoder.py:105-113)
+  TRY(gava::patch_gather(x, w.PATCH, m->B, m->T_in, m->size, m->P, Kp, pr, s));
+  {
+    gava_gemm_args a{};
+    a.A = w.PATCH; a.lda = Kp; a.W = m->w_patch; a.ldw = Kp; a.bias = m->b_patch;
+    a.out = w.X; a.ldo = D; a.M = BT * n; a.N = D; a.K = Kp; a.epilogue = GAVA_EPI_F32_PATCH; a.prec = pr;
+    a.pos = m->pos_embed; a.time = m->time_embed; a.n_patches = n; a.T = m->T_in;
+    TRY(gava_gemm(&a, stream));
+  }
+  TRY(gava::cls_embed(w.X, m->cls_token, m->pos_embed, m->time_embed, BT, m->T_in, D, fs, s));
+  TRY(ln(w.X, D, nullptr, m->lnpre_g, m->lnpre_b, nullptr, 0, w.X, D, R, D, pr, stream));
+
+  // ---- blocks (VitaCLIP_vision_encoder.py:115-121, VitaCLIP_vision_encoder_utils.py:155-203)
+  for (int i = 0; i < m->layers; ++i) {
+    const gava_vision_layer& L = m->layer[i];
+    const unsigned short* wqkv = (const unsigned short*)L.w_qkv;
+    // prompt ("side") path: cls_proj, summary token, local prompts -> K/V-only rows
+    TRY(ln(w.X, fs, nullptr, nullptr, nullptr, w.CLS16, D, nullptr, 0, BT, D, pr, stream));
+    TRY(gemm(w.CLS16, D, L.w_cls, D, L.b_cls, w.CP, D, BT, D, D, GAVA_EPI_F32, pr, stream));
+    TRY(ln(w.CP, D, nullptr, L.sln_g, L.sln_b, w.CPn, D, nullptr, 0, BT, D, pr, stream));
+    TRY(gemm(w.CPn, D, L.w_sqkv, D, L.b_sqkv, w.SQKV, 3 * D, BT, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+    {
+      gava_attention_args a{};
+      const unsigned short* q = (const unsigned short*)w.SQKV;
+      a.q = q; a.k = q + D; a.v = q + 2 * D; a.ld_qkv = 3 * D; a.out = w.SMIX; a.ld_out = D;
+      a.batch = BT / Tm; a.heads = m->H; a.n_q = Tm; a.n_kmain = Tm; a.prec = pr;
+      TRY(gava_attention(&a, stream));
+    }
+    TRY(gemm(w.SMIX, D, L.w_sout, D, L.b_sout, w.SUMM, D, BT, D, D, GAVA_EPI_F32, pr, stream, w.CP, D));
+    TRY(gava::side_ln(L.global_prompts, L.local_prompts, w.CP, w.SUMM, L.ln1_g, L.ln1_b, w.SIDEn, G, Tm, BT, D, pr, s));
+    TRY(gemm(w.SIDEn, D, wqkv + (long)D * D, D, L.b_qkv + D, w.SIDEKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, stream));
+    // main path
+    TRY(ln(w.X, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
+    TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+    {
+      gava_attention_args a{};
+      const unsigned short* q = (const unsigned short*)w.QKV;
+      const unsigned short* sk = (const unsigned short*)w.SIDEKV;
+      a.q = q; a.k = q + D; a.v = q + 2 * D; a.ld_qkv = 3 * D;
+      a.side_k = sk; a.side_v = sk + D; a.ld_side = 2 * D;
+      a.out = w.MIX; a.ld_out = D;
+      a.batch = BT; a.heads = m->H; a.n_q = n + 1; a.n_kmain = n + 1;
+      a.n_g = G; a.T = Tm; a.has_summary = 1; a.prec = pr;
+      TRY(gava_attention(&a, stream));
+    }
+    TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D));
+    TRY(ln(w.X, D, nullptr, L.ln2_g, L.ln2_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
+    TRY(gemm(w.Xn, D, L.w_fc1, D, L.b_fc1, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream));
+    TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D));
+    if (debug_cls) TRY(gava::copy_rows(w.X, fs, debug_cls + (long)i * BT * D, BT, D, s));
+  }
+
+  // ---- head (VitaCLIP_vision_encoder.py:126-130)
+  TRY(ln(w.X, fs, nullptr, m->lnpost_g, m->lnpost_b, w.CLSPOST, D, nullptr, 0, BT, D, pr, stream));
+  TRY(gemm(w.CLSPOST, D, m->w_proj, D, nullptr, w.PROJ, E, BT, E, D, GAVA_EPI_F32, pr, stream));
+  TRY(gava::mean_rows(w.PROJ, cls_x, m->B, m->T_in, E, s));
+  TRY(gava::mean_rows(w.SUMM, summary, BT / Tm, Tm, D, s));
+  return GAVA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct TextWs { float* X; void* Xn; void* QKV; void* MIX; void* HID; void* EOT16; size_t total; };
+
+TextWs carve_text(const gava_text_model* m, void* ws, size_t cap) {
+  const long R = (long)m->n_prompts * m->L, W = m->W;
+  Carver c(ws, cap);
+  TextWs w;
+  w.X = (float*)c.take(R * W * 4);
+  w.Xn = c.take(R * W * 2);
+  w.QKV = c.take(R * 3 * W * 2);
+  w.MIX = c.take(R * W * 2);
+  w.HID = c.take(R * 4 * W * 2);
+  w.EOT16 = c.take((long)m->n_prompts * W * 2);
+  w.total = (c.off + 255) & ~(size_t)255;
+  return w;
+}
+
+int check_text(const gava_text_model* m) {
+  if (!m || !m->layer) return GAVA_EINVAL;
+  if (m->n_prompts <= 0 || m->L <= 0 || m->L > 320 || m->layers <= 0) return GAVA_EINVAL;
+  if (m->W != m->H * 64 || m->W % 128 || m->E % 128 || m->W > 1024) return GAVA_EINVAL;
+  if (m->n_ctx < 0 || m->n_ctx + 1 >= m->L) return GAVA_EINVAL;
+  return GAVA_OK;
+}
+}  // namespace
+
+extern "C" size_t gava_text_workspace_bytes(const gava_text_model* m) {
+  if (check_text(m) != GAVA_OK) return 0;
+  return carve_text(m, nullptr, 0).total;
+}
+
+extern "C" int gava_text_forward(const gava_text_model* m, const int32_t* tokens, const float* ctx,
+                                 const int32_t* eot_index, float* out, void* workspace, size_t workspace_bytes,
+                                 gava_stream_t stream) {
+  TRY(check_text(m));
+  if (!tokens || !ctx || !eot_index || !out || !workspace) return GAVA_EINVAL;
+  const TextWs w = carve_text(m, workspace, workspace_bytes);
+  if (w.total > workspace_bytes) return GAVA_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int R = m->n_prompts * m->L, W = m->W, pr = m->prec;
+  TRY(gava::text_embed(m->token_embedding, m->positional_embedding, ctx, tokens, w.X, m->n_prompts, m->L, W, m->n_ctx, s));
+  for (int i = 0; i < m->layers; ++i) {
+    const gava_text_layer& L = m->layer[i];
+    TRY(ln(w.X, W, nullptr, L.ln1_g, L.ln1_b, w.Xn, W, nullptr, 0, R, W, pr, stream));
+    TRY(gemm(w.Xn, W, L.w_qkv, W, L.b_qkv, w.QKV, 3 * W, R, 3 * W, W, GAVA_EPI_H16, pr, stream, nullptr, 0, W, 0.125f));
+    {
+      gava_attention_args a{};
+      const unsigned short* q = (const unsigned short*)w.QKV;
+      a.q = q; a.k = q + W; a.v = q + 2 * W; a.ld_qkv = 3 * W; a.out = w.MIX; a.ld_out = W;
+      a.batch = m->n_prompts; a.heads = m->H; a.n_q = m->L; a.n_kmain = m->L; a.causal = 1; a.prec = pr;
+      TRY(gava_attention(&a, stream));
+    }
+    TRY(gemm(w.MIX, W, L.w_out, W, L.b_out, w.X, W, R, W, W, GAVA_EPI_F32, pr, stream, w.X, W));
+    TRY(ln(w.X, W, nullptr, L.ln2_g, L.ln2_b, w.Xn, W, nullptr, 0, R, W, pr, stream));
+    TRY(gemm(w.Xn, W, L.w_fc, W, L.b_fc, w.HID, 4 * W, R, 4 * W, W, GAVA_EPI_H16_QGELU, pr, stream));
+    TRY(gemm(w.HID, 4 * W, L.w_proj, 4 * W, L.b_proj, w.X, W, R, W, 4 * W, GAVA_EPI_F32, pr, stream, w.X, W));
+  }
+  // ln_final on the EOT rows only, then text_projection (VitaCLIP_text_encoder.py:164-169)
+  TRY(ln(w.X, W, eot_index, m->lnf_g, m->lnf_b, w.EOT16, W, nullptr, 0, m->n_prompts, W, pr, stream));
+  TRY(gemm(w.EOT16, W, m->w_tproj, W, nullptr, out, m->E, m->n_prompts, m->E, W, GAVA_EPI_F32, pr, stream));
+  return GAVA_OK;
+}

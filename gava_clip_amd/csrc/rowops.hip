@@ -1,0 +1,370 @@
+// rowops.hip — HBM-bound row kernels: LayerNorm, conversions, token/prompt assembly, pooling,
+// similarity head.  One 64-lane wave owns one row (float4 per lane, fully coalesced 1 KiB per
+// wave instruction); statistics are reduced with cross-lane shuffles, no LDS.
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int MAXV = 4;  // float4 per lane: D <= 1024
+
+template <class P>
+static __device__ __forceinline__ void store_h16x4(unsigned short* dst, float4 v) {
+  *reinterpret_cast<uint2*>(dst) = pack4<P>(v.x, v.y, v.z, v.w);
+}
+
+// normalise a row held as v[0..nv) float4 per lane; eps = 1e-5, two-pass statistics
+static __device__ __forceinline__ void ln_row(float4 (&v)[MAXV], int nv_lane_count, int D,
+                                              const bool (&act)[MAXV]) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (act[i]) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (act[i]) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (act[i]) { v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd; }
+  (void)nv_lane_count;
+}
+
+struct LnParams {
+  const float* in; long in_stride; const int* idx;
+  const float* gamma; const float* beta;
+  unsigned short* out16; long o16_stride;
+  float* out32; long o32_stride;
+  int rows, D;
+};
+
+template <class P>
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const long src_row = p.idx ? (long)p.idx[row] : (long)row;
+  const float* src = p.in + src_row * p.in_stride;
+  float4 v[MAXV];
+  bool act[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    act[i] = c < p.D;
+    if (act[i]) v[i] = *reinterpret_cast<const float4*>(src + c);
+  }
+  if (p.gamma) {
+    ln_row(v, 0, p.D, act);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (act[i]) {
+        const int c = (lane + 64 * i) * 4;
+        const float4 g = *reinterpret_cast<const float4*>(p.gamma + c);
+        const float4 b = *reinterpret_cast<const float4*>(p.beta + c);
+        v[i].x = v[i].x * g.x + b.x; v[i].y = v[i].y * g.y + b.y;
+        v[i].z = v[i].z * g.z + b.z; v[i].w = v[i].w * g.w + b.w;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (act[i]) {
+      const int c = (lane + 64 * i) * 4;
+      if (p.out16) store_h16x4<P>(p.out16 + (long)row * p.o16_stride + c, v[i]);
+      if (p.out32) *reinterpret_cast<float4*>(p.out32 + (long)row * p.o32_stride + c) = v[i];
+    }
+}
+
+// ---- vision "side" rows: assemble [global prompts | local prompts + cls_proj | summary] and
+// apply norm1 -> h16 (the K/V-only tokens of VitaCLIP_vision_encoder_utils.py:171-190).
+struct SideParams {
+  const float* gp;      // [G][D]
+  const float* lp;      // [T][D]
+  const float* cp;      // [BT][D] cls_proj output
+  const float* summ;    // [BT][D] summary token
+  const float* gamma; const float* beta;
+  unsigned short* out;  // [G + 2*BT][D]
+  int G, T, BT, D;
+};
+
+template <class P>
+__global__ __launch_bounds__(256) void side_ln_kernel(const SideParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.G + 2 * p.BT) return;
+  float4 v[MAXV];
+  bool act[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    act[i] = c < p.D;
+    if (!act[i]) continue;
+    if (row < p.G) {
+      v[i] = *reinterpret_cast<const float4*>(p.gp + (long)row * p.D + c);
+    } else if (row < p.G + p.BT) {
+      const int f = row - p.G;
+      const float4 a = *reinterpret_cast<const float4*>(p.lp + (long)(f % p.T) * p.D + c);
+      const float4 b = *reinterpret_cast<const float4*>(p.cp + (long)f * p.D + c);
+      v[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    } else {
+      v[i] = *reinterpret_cast<const float4*>(p.summ + (long)(row - p.G - p.BT) * p.D + c);
+    }
+  }
+  ln_row(v, 0, p.D, act);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (act[i]) {
+      const int c = (lane + 64 * i) * 4;
+      const float4 g = *reinterpret_cast<const float4*>(p.gamma + c);
+      const float4 b = *reinterpret_cast<const float4*>(p.beta + c);
+      store_h16x4<P>(p.out + (long)row * p.D + c,
+                     make_float4(v[i].x * g.x + b.x, v[i].y * g.y + b.y, v[i].z * g.z + b.z, v[i].w * g.w + b.w));
+    }
+}
+
+// ---- patch gather: x (B,3,T,S,S) fp32 -> patch matrix [BT*n][Kp] h16, k = (c,ky,kx), zero
+// padded to Kp.  One thread converts 4 consecutive kx (16 B read, 8 B write).
+template <class P>
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
+                                                           int B, int T, int S, int Pp, int Kp, long total4) {
+  const int g = S / Pp, n = g * g, K = 3 * Pp * Pp;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total4; id += (long)gridDim.x * blockDim.x) {
+    const int k4 = (int)(id % (Kp / 4));
+    const long prow = id / (Kp / 4);
+    const int k = k4 * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < K) {
+      const int c = k / (Pp * Pp), rem = k - c * Pp * Pp, ky = rem / Pp, kx = rem - ky * Pp;
+      const int pp = (int)(prow % n);
+      const long frame = prow / n;
+      const int b = (int)(frame / T), t = (int)(frame % T);
+      const int py = pp / g, px = pp - py * g;
+      const float* src = x + ((((long)b * 3 + c) * T + t) * S + (py * Pp + ky)) * S + px * Pp + kx;
+      if ((Pp & 3) == 0) {
+        v = *reinterpret_cast<const float4*>(src);
+      } else {  // patch width not a multiple of 4 (P=14): 4 k's may wrap to the next ky row
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kj = k + j;
+          if (kj < K) {
+            const int cj = kj / (Pp * Pp), rj = kj - cj * Pp * Pp, kyj = rj / Pp, kxj = rj - kyj * Pp;
+            e[j] = x[((((long)b * 3 + cj) * T + t) * S + (py * Pp + kyj)) * S + px * Pp + kxj];
+          } else e[j] = 0.f;
+        }
+        v = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    }
+    store_h16x4<P>(out + prow * Kp + k, v);
+  }
+}
+
+// cls rows of the embedding: X[frame*(n+1)] = cls_token + pos[0] + time[frame % T]
+__global__ void cls_embed_kernel(float* X, const float* cls, const float* pos, const float* time,
+                                 int BT, int T, int D, long frame_stride) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)BT * D) return;
+  const int c = (int)(id % D);
+  const long f = id / D;
+  X[f * frame_stride + c] = cls[c] + pos[c] + time[(f % T) * D + c];
+}
+
+// out[b][c] = mean_t in[(b*T+t)][c]
+__global__ void mean_rows_kernel(const float* in, float* out, int B, int T, int D) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)B * D) return;
+  const int c = (int)(id % D);
+  const long b = id / D;
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += in[(b * T + t) * D + c];
+  out[id] = s / (float)T;
+}
+
+// copy strided rows (debug taps)
+__global__ void copy_rows_kernel(const float* in, long in_stride, float* out, int rows, int D) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)rows * D) return;
+  out[id] = in[(id / D) * in_stride + id % D];
+}
+
+// text prompt assembly + positional embedding (VitaCLIP_text_encoder.py:323-332,155):
+// X[n][l] = (l==0 ? emb[tok[n][0]] : l<=n_ctx ? ctx[n][l-1] : emb[tok[n][l]]) + pos[l]
+__global__ void text_embed_kernel(const float* emb, const float* pos, const float* ctx, const int* tok,
+                                  float* X, int n_prompts, int L, int W, int n_ctx) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)n_prompts * L * W) return;
+  const int c = (int)(id % W);
+  const long row = id / W;
+  const int l = (int)(row % L);
+  const long n = row / L;
+  float v;
+  if (l >= 1 && l <= n_ctx) v = ctx[(n * n_ctx + (l - 1)) * W + c];
+  else v = emb[(long)tok[n * L + l] * W + c];
+  X[id] = v + pos[(long)l * W + c];
+}
+
+template <class P>
+__global__ void convert_kernel(const float* in, unsigned short* out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = P::cvt(in[i]);
+}
+
+// ---- similarity head, all fp32 (VitaCLIP_model.py:255,287-293).  One wave per output.
+__global__ void l2norm_rows_kernel(const float* in, float* out, int rows, int E) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < E; c += 64) { const float v = in[(long)row * E + c]; s += v * v; }
+  const float inv = 1.0f / sqrtf(wave_sum(s));
+  for (int c = lane; c < E; c += 64) out[(long)row * E + c] = in[(long)row * E + c] * inv;
+}
+
+__global__ void logits_kernel(const float* vn, const float* tn, const float* logit_scale, const float* logit_bias,
+                              int B, int C, int n_kv, int E, float* logits) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= B * C) return;
+  const int b = o / C, c = o % C;
+  const float ls = expf(logit_scale[0]);
+  float acc = 0.f;
+  for (int k = 0; k < n_kv; ++k) {
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s += vn[(long)b * E + e] * tn[((long)c * n_kv + k) * E + e];
+    acc += ls * wave_sum(s);
+  }
+  acc /= (float)n_kv;
+  if (logit_bias) acc += logit_bias[0];
+  if (lane == 0) logits[o] = acc;
+}
+
+// text_features[c] = normalise(mean_k tn[c][k])
+__global__ void text_feature_kernel(const float* tn, float* tf, int C, int n_kv, int E) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  float s = 0.f;
+  for (int e = lane; e < E; e += 64) {
+    float m = 0.f;
+    for (int k = 0; k < n_kv; ++k) m += tn[((long)c * n_kv + k) * E + e];
+    m /= (float)n_kv;
+    s += m * m;
+  }
+  const float inv = 1.0f / sqrtf(wave_sum(s));
+  for (int e = lane; e < E; e += 64) {
+    float m = 0.f;
+    for (int k = 0; k < n_kv; ++k) m += tn[((long)c * n_kv + k) * E + e];
+    tf[(long)c * E + e] = (m / (float)n_kv) * inv;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int gava_layernorm(const gava_layernorm_args* a, gava_stream_t stream) {
+  if (!a || !a->in || a->rows <= 0) return GAVA_EINVAL;
+  if (a->D % 4 || a->D > 256 * MAXV || a->D <= 0) return GAVA_EINVAL;
+  if (!a->out16 && !a->out32) return GAVA_EINVAL;
+  if (a->gamma && !a->beta) return GAVA_EINVAL;
+  if (a->in_stride % 4 || (a->out16 && a->out16_stride % 4) || (a->out32 && a->out32_stride % 4)) return GAVA_EINVAL;
+  LnParams p{a->in, a->in_stride, a->in_row_index, a->gamma, a->beta, (unsigned short*)a->out16,
+             a->out16_stride, a->out32, a->out32_stride, a->rows, a->D};
+  dim3 grid((a->rows + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (a->prec == GAVA_PREC_F16) hipLaunchKernelGGL(layernorm_kernel<PrecF16>, grid, block, 0, s, p);
+  else if (a->prec == GAVA_PREC_BF16) hipLaunchKernelGGL(layernorm_kernel<PrecBF16>, grid, block, 0, s, p);
+  else return GAVA_EINVAL;
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+extern "C" int gava_convert_h16(const float* in, void* out, size_t n, int prec, gava_stream_t stream) {
+  if (!in || !out) return GAVA_EINVAL;
+  if (n == 0) return GAVA_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  if (prec == GAVA_PREC_F16) hipLaunchKernelGGL(convert_kernel<PrecF16>, dim3(blocks), dim3(256), 0, s, in, (unsigned short*)out, n);
+  else if (prec == GAVA_PREC_BF16) hipLaunchKernelGGL(convert_kernel<PrecBF16>, dim3(blocks), dim3(256), 0, s, in, (unsigned short*)out, n);
+  else return GAVA_EINVAL;
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+extern "C" int gava_similarity_head(const float* video, const float* text, const float* logit_scale,
+                                    const float* logit_bias, int B, int C, int n_kv, int E, float* logits,
+                                    float* text_features, float* video_norm, gava_stream_t stream) {
+  // video_norm doubles as scratch for the normalised video rows; text rows are normalised into
+  // text_features' tail when n_kv == 1, otherwise the caller must pass n_kv == 1 (the only
+  // configuration reachable without the KAPT data files).
+  if (!video || !text || !logit_scale || !logits || !text_features || !video_norm) return GAVA_EINVAL;
+  if (B <= 0 || C <= 0 || E <= 0 || n_kv != 1) return GAVA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, s, video, video_norm, B, E);
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((C + 3) / 4), dim3(256), 0, s, text, text_features, C, E);
+  hipLaunchKernelGGL(logits_kernel, dim3((B * C + 3) / 4), dim3(256), 0, s, video_norm, text_features, logit_scale,
+                     logit_bias, B, C, 1, E, logits);
+  // second normalisation of the per-class mean (VitaCLIP_model.py:290-291); with n_kv == 1 the
+  // mean is the row itself, so this re-normalises an already unit row exactly as upstream does.
+  hipLaunchKernelGGL(text_feature_kernel, dim3((C + 3) / 4), dim3(256), 0, s, text_features, text_features, C, 1, E);
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+// ---- internal launchers used by the fused drivers -------------------------------------------
+namespace gava {
+
+int side_ln(const float* gp, const float* lp, const float* cp, const float* summ, const float* gamma,
+            const float* beta, void* out, int G, int T, int BT, int D, int prec, hipStream_t s) {
+  SideParams p{gp, lp, cp, summ, gamma, beta, (unsigned short*)out, G, T, BT, D};
+  const int rows = G + 2 * BT;
+  if (prec == GAVA_PREC_F16) hipLaunchKernelGGL(side_ln_kernel<PrecF16>, dim3((rows + 3) / 4), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(side_ln_kernel<PrecBF16>, dim3((rows + 3) / 4), dim3(256), 0, s, p);
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+int patch_gather(const float* x, void* out, int B, int T, int S, int P, int Kp, int prec, hipStream_t s) {
+  const int g = S / P;
+  const long total4 = (long)B * T * g * g * (Kp / 4);
+  const int blocks = (int)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
+  if (prec == GAVA_PREC_F16) hipLaunchKernelGGL(patch_gather_kernel<PrecF16>, dim3(blocks), dim3(256), 0, s, x, (unsigned short*)out, B, T, S, P, Kp, total4);
+  else hipLaunchKernelGGL(patch_gather_kernel<PrecBF16>, dim3(blocks), dim3(256), 0, s, x, (unsigned short*)out, B, T, S, P, Kp, total4);
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+int cls_embed(float* X, const float* cls, const float* pos, const float* time, int BT, int T, int D,
+              long frame_stride, hipStream_t s) {
+  const long n = (long)BT * D;
+  hipLaunchKernelGGL(cls_embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, cls, pos, time, BT, T, D, frame_stride);
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+int mean_rows(const float* in, float* out, int B, int T, int D, hipStream_t s) {
+  const long n = (long)B * D;
+  hipLaunchKernelGGL(mean_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, B, T, D);
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+int copy_rows(const float* in, long in_stride, float* out, int rows, int D, hipStream_t s) {
+  const long n = (long)rows * D;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, in_stride, out, rows, D);
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+int text_embed(const float* emb, const float* pos, const float* ctx, const int* tok, float* X,
+               int n_prompts, int L, int W, int n_ctx, hipStream_t s) {
+  const long n = (long)n_prompts * L * W;
+  hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, emb, pos, ctx, tok, X, n_prompts, L, W, n_ctx);
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+}  // namespace gava

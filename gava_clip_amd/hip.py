@@ -1,0 +1,181 @@
+"""ctypes binding of libgava_hip.so (include/gava_hip.h).
+
+The product path has NO fallback: if the library is missing or a call is rejected this module
+raises.  torch is used only to own device memory and to name the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgava_hip.so")
+
+PREC_F16, PREC_BF16 = 0, 1
+EPI_H16, EPI_H16_QGELU, EPI_F32, EPI_F32_PATCH = 0, 1, 2, 3
+PREC_NAMES = {"fp16": PREC_F16, "f16": PREC_F16, "bf16": PREC_BF16}
+PREC_TORCH = {PREC_F16: torch.float16, PREC_BF16: torch.bfloat16}
+
+EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
+           "gava_vision_workspace_bytes", "gava_vision_forward", "gava_text_workspace_bytes",
+           "gava_text_forward", "gava_similarity_head", "gava_convert_h16"]
+
+_vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", _vp), ("lda", C.c_int64), ("W", _vp), ("ldw", C.c_int64), ("bias", _fp),
+                ("out", _vp), ("ldo", C.c_int64), ("resid", _fp), ("ldr", C.c_int64),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int), ("prec", C.c_int),
+                ("scale_cols", C.c_int), ("scale", C.c_float),
+                ("pos", _fp), ("time", _fp), ("n_patches", C.c_int), ("T", C.c_int)]
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = [("inp", _fp), ("in_stride", C.c_int64), ("in_row_index", _ip), ("gamma", _fp), ("beta", _fp),
+                ("out16", _vp), ("out16_stride", C.c_int64), ("out32", _fp), ("out32_stride", C.c_int64),
+                ("rows", C.c_int), ("D", C.c_int), ("prec", C.c_int)]
+
+
+class AttentionArgs(C.Structure):
+    _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("ld_qkv", C.c_int64),
+                ("side_k", _vp), ("side_v", _vp), ("ld_side", C.c_int64),
+                ("out", _vp), ("ld_out", C.c_int64),
+                ("batch", C.c_int), ("heads", C.c_int), ("n_q", C.c_int), ("n_kmain", C.c_int),
+                ("n_g", C.c_int), ("T", C.c_int), ("has_summary", C.c_int),
+                ("causal", C.c_int), ("prec", C.c_int)]
+
+
+class VisionLayer(C.Structure):
+    _fields_ = [(n, _vp) for n in (
+        "w_qkv", "b_qkv", "w_out", "b_out", "w_fc1", "b_fc1", "w_fc2", "b_fc2",
+        "ln1_g", "ln1_b", "ln2_g", "ln2_b", "w_cls", "b_cls", "sln_g", "sln_b",
+        "w_sqkv", "b_sqkv", "w_sout", "b_sout", "local_prompts", "global_prompts")]
+
+
+class VisionModel(C.Structure):
+    _fields_ = [("B", C.c_int), ("T_in", C.c_int), ("T_model", C.c_int),
+                ("size", C.c_int), ("P", C.c_int), ("D", C.c_int), ("H", C.c_int), ("layers", C.c_int),
+                ("F", C.c_int), ("E", C.c_int), ("G", C.c_int), ("prec", C.c_int),
+                ("w_patch", _vp), ("b_patch", _fp), ("cls_token", _fp), ("pos_embed", _fp), ("time_embed", _fp),
+                ("lnpre_g", _fp), ("lnpre_b", _fp), ("lnpost_g", _fp), ("lnpost_b", _fp),
+                ("w_proj", _vp), ("layer", C.POINTER(VisionLayer))]
+
+
+class TextLayer(C.Structure):
+    _fields_ = [(n, _vp) for n in (
+        "w_qkv", "b_qkv", "w_out", "b_out", "w_fc", "b_fc", "w_proj", "b_proj",
+        "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+
+
+class TextModel(C.Structure):
+    _fields_ = [("n_prompts", C.c_int), ("L", C.c_int), ("W", C.c_int), ("H", C.c_int), ("layers", C.c_int),
+                ("E", C.c_int), ("n_ctx", C.c_int), ("prec", C.c_int),
+                ("token_embedding", _fp), ("positional_embedding", _fp), ("lnf_g", _fp), ("lnf_b", _fp),
+                ("w_tproj", _vp), ("layer", C.POINTER(TextLayer))]
+
+
+_lib = None
+
+
+class GavaError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "GAVA_EINVAL (unsupported shape/alignment)", -2: "GAVA_EWORKSPACE (workspace too small)",
+        -3: "GAVA_ELAUNCH (kernel launch failed)"}
+
+
+def load():
+    """Load libgava_hip.so; raises GavaError when it has not been built (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GavaError(f"{LIB_PATH} is missing: run `python -m gava_clip_amd.build` "
+                        "(the HIP path has no fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.gava_abi_version.restype = C.c_int
+    for name, args in (("gava_gemm", [C.POINTER(GemmArgs), _vp]),
+                       ("gava_layernorm", [C.POINTER(LayerNormArgs), _vp]),
+                       ("gava_attention", [C.POINTER(AttentionArgs), _vp])):
+        f = getattr(lib, name)
+        f.argtypes, f.restype = args, C.c_int
+    lib.gava_vision_workspace_bytes.argtypes = [C.POINTER(VisionModel)]
+    lib.gava_vision_workspace_bytes.restype = C.c_size_t
+    lib.gava_vision_forward.argtypes = [C.POINTER(VisionModel), _fp, _fp, _fp, _fp, _vp, C.c_size_t, _vp]
+    lib.gava_vision_forward.restype = C.c_int
+    lib.gava_text_workspace_bytes.argtypes = [C.POINTER(TextModel)]
+    lib.gava_text_workspace_bytes.restype = C.c_size_t
+    lib.gava_text_forward.argtypes = [C.POINTER(TextModel), _ip, _fp, _ip, _fp, _vp, C.c_size_t, _vp]
+    lib.gava_text_forward.restype = C.c_int
+    lib.gava_similarity_head.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _vp]
+    lib.gava_similarity_head.restype = C.c_int
+    lib.gava_convert_h16.argtypes = [_fp, _vp, C.c_size_t, C.c_int, _vp]
+    lib.gava_convert_h16.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise GavaError(f"{what} failed: {_ERR.get(code, code)}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda, "gava_clip_amd kernels take device tensors only"
+    return C.c_void_p(t.data_ptr())
+
+
+def h16_dtype(prec):
+    return PREC_TORCH[prec]
+
+
+# ---- thin per-op wrappers (used by the unit tests; the model uses the fused drivers) ----------
+
+def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0,
+         pos=None, time=None, n_patches=0, T=0, M=None):
+    a = GemmArgs()
+    a.A, a.lda, a.W, a.ldw = ptr(A), A.stride(0), ptr(W), W.stride(0)
+    a.bias, a.out, a.ldo = ptr(bias), ptr(out), out.stride(0)
+    a.resid, a.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
+    a.M, a.N, a.K = (A.shape[0] if M is None else M), W.shape[0], W.shape[1]
+    a.epilogue, a.prec, a.scale_cols, a.scale = epilogue, prec, scale_cols, scale
+    a.pos, a.time, a.n_patches, a.T = ptr(pos), ptr(time), n_patches, T
+    check(load().gava_gemm(C.byref(a), stream_ptr()), "gava_gemm")
+
+
+def layernorm(x, gamma, beta, *, out16=None, out32=None, prec, rows=None, in_stride=None, row_index=None):
+    a = LayerNormArgs()
+    a.inp, a.in_stride, a.in_row_index = ptr(x), (x.stride(0) if in_stride is None else in_stride), ptr(row_index)
+    a.gamma, a.beta = ptr(gamma), ptr(beta)
+    a.out16, a.out16_stride = ptr(out16), (out16.stride(0) if out16 is not None else 0)
+    a.out32, a.out32_stride = ptr(out32), (out32.stride(0) if out32 is not None else 0)
+    a.rows, a.D, a.prec = (x.shape[0] if rows is None else rows), x.shape[-1], prec
+    check(load().gava_layernorm(C.byref(a), stream_ptr()), "gava_layernorm")
+
+
+def attention(q, k, v, out, *, batch, heads, n_q, n_kmain, prec, causal=False,
+              side_k=None, side_v=None, n_g=0, T=0, has_summary=False):
+    a = AttentionArgs()
+    a.q, a.k, a.v, a.ld_qkv = ptr(q), ptr(k), ptr(v), q.stride(0)
+    a.side_k, a.side_v = ptr(side_k), ptr(side_v)
+    a.ld_side = side_k.stride(0) if side_k is not None else 0
+    a.out, a.ld_out = ptr(out), out.stride(0)
+    a.batch, a.heads, a.n_q, a.n_kmain = batch, heads, n_q, n_kmain
+    a.n_g, a.T, a.has_summary, a.causal, a.prec = n_g, T, int(has_summary), int(causal), prec
+    check(load().gava_attention(C.byref(a), stream_ptr()), "gava_attention")
+
+
+def convert_h16(x, prec):
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=h16_dtype(prec), device=x.device)
+    check(load().gava_convert_h16(ptr(x), ptr(out), x.numel(), prec, stream_ptr()), "gava_convert_h16")
+    return out

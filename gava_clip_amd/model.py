@@ -1,0 +1,531 @@
+"""Drop-in ``VitaCLIP(nn.Module)`` whose forward runs on libgava_hip.so (MI355X / gfx950).
+
+Mirrors the reference boundary /root/reference/training/VitaCLIP_model.py:22-401: same
+constructor keywords (:24-74), same ``forward(x, memory=None, video_nte=None, desc_wise=False)``
+-> ``(logits, logits_mt, logits_vm)`` (:241-244,401), same ``state_dict`` keys,
+same public attributes (``visual``, ``textual``, ``prompt_learner``, ``tokenized_prompts``,
+``logit_scale``, ``text_features``), same freezing of parameters (:222-239).
+
+The sub-modules below are parameter containers with the reference's names and initialisers; they
+compute nothing in PyTorch.  All arithmetic of the hot path happens in the HIP kernels through
+the C ABI (gava_clip_amd/hip.py); PyTorch only owns the device memory.  There is no CPU or eager
+fallback: a non-device input or a missing library raises.
+"""
+import ctypes as C
+import math
+import os
+from collections import OrderedDict
+from typing import List, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip
+from .tokenizer import tokenize, read_class_names, prompt_texts
+
+NUM_COMB = 70  # /root/reference/video_dataset/dataset.py:19
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter containers (names/initialisers: VitaCLIP_vision_encoder*.py, VitaCLIP_text_encoder.py)
+# ---------------------------------------------------------------------------------------------
+class _Params(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover - never called
+        raise RuntimeError("gava_clip_amd sub-modules hold parameters only; call VitaCLIP.forward")
+
+
+class Attention(_Params):
+    """q/k/v/out projections (VitaCLIP_vision_encoder_utils.py:31-57)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.q_proj = nn.Linear(dim, dim)
+        self.k_proj = nn.Linear(dim, dim)
+        self.v_proj = nn.Linear(dim, dim)
+        self.out_proj = nn.Linear(dim, dim)
+        for m in (self.q_proj, self.k_proj, self.v_proj, self.out_proj):
+            nn.init.xavier_uniform_(m.weight)
+            nn.init.constant_(m.bias, 0.)
+
+
+class LayerNorm(nn.LayerNorm):
+    pass
+
+
+class TransformerEncoderLayer(_Params):
+    """VitaCLIP_vision_encoder_utils.py:83-152 (summary token and local prompts always on)."""
+
+    def __init__(self, dim, num_heads, mlp_factor, num_frames, patch_size):
+        super().__init__()
+        self.attn = Attention(dim)
+        mlp_dim = round(mlp_factor * dim)
+        self.mlp = nn.Sequential(OrderedDict([("fc1", nn.Linear(dim, mlp_dim)), ("act", nn.Identity()),
+                                              ("dropout", nn.Identity()), ("fc2", nn.Linear(mlp_dim, dim))]))
+        self.norm1 = LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
+        self.cls_proj = nn.Linear(dim, dim)
+        self.num_frames = num_frames
+        self.summary_ln = LayerNorm(dim)
+        self.summary_attn_layer = Attention(dim)
+        self.local_prompts = nn.Parameter(torch.zeros(1, num_frames, dim))
+        val = math.sqrt(6. / float(3 * patch_size[0] * patch_size[1] + dim))
+        nn.init.uniform_(self.local_prompts.data, -val, val)
+        for m in (self.mlp.fc1, self.mlp.fc2):
+            nn.init.xavier_uniform_(m.weight)
+            nn.init.normal_(m.bias, std=1e-6)
+
+
+class _PatchEmbed(_Params):
+    def __init__(self, patch, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
+
+
+class CLIPVisionEncoder(_Params):
+    """VitaCLIP_vision_encoder.py:19-84."""
+
+    def __init__(self, input_size, num_frames, feature_dim, patch_size, num_heads, num_layers, mlp_factor,
+                 embed_dim, num_global_prompts):
+        super().__init__()
+        self.feature_dim = feature_dim
+        self.patch_embed = _PatchEmbed(patch_size[0], feature_dim)
+        self.num_patches = int(np.prod([x // y for x, y in zip(input_size, patch_size)])) + 1
+        self.cls_token = nn.Parameter(torch.zeros([feature_dim]))
+        self.pos_embed = nn.Parameter(torch.zeros([self.num_patches, feature_dim]))
+        self.time_embed = nn.Parameter(torch.zeros([num_frames, feature_dim]))
+        self.blocks = nn.ModuleList([TransformerEncoderLayer(feature_dim, num_heads, mlp_factor, num_frames, patch_size)
+                                     for _ in range(num_layers)])
+        self.ln_pre = LayerNorm(feature_dim)
+        self.ln_post = LayerNorm(feature_dim)
+        self.proj = nn.Parameter(feature_dim ** -0.5 * torch.randn(feature_dim, embed_dim))
+        self.use_global_prompts = True
+        self.num_global_prompts = num_global_prompts
+        self.global_prompts = nn.Parameter(torch.zeros(num_layers, num_global_prompts, feature_dim))
+        val = math.sqrt(6. / float(3 * patch_size[0] * patch_size[1] + feature_dim))
+        nn.init.uniform_(self.global_prompts.data, -val, val)
+        nn.init.normal_(self.cls_token, std=0.02)
+        nn.init.normal_(self.pos_embed, std=0.02)
+        nn.init.normal_(self.time_embed, std=0.02)
+
+
+class _MHAParams(_Params):
+    """Parameter layout of nn.MultiheadAttention (packed in_proj), VitaCLIP_text_encoder.py:71."""
+
+    def __init__(self, width):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * width, width))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * width))
+        self.out_proj = nn.Linear(width, width)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.)
+
+
+class ResidualAttentionBlock(_Params):
+    def __init__(self, width):
+        super().__init__()
+        self.attn = _MHAParams(width)
+        self.ln_1 = LayerNorm(width)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(width, width * 4)), ("gelu", nn.Identity()),
+                                              ("c_proj", nn.Linear(width * 4, width))]))
+        self.ln_2 = LayerNorm(width)
+
+
+class Transformer(_Params):
+    def __init__(self, width, layers):
+        super().__init__()
+        self.width, self.layers = width, layers
+        self.resblocks = nn.ModuleList([ResidualAttentionBlock(width) for _ in range(layers)])
+
+
+class CLIPTextEncoder(_Params):
+    """VitaCLIP_text_encoder.py:120-143.  positional_embedding / text_projection are
+    ``torch.empty`` upstream (uninitialised without a checkpoint); here they get the CLIP
+    initialisers so that a random-weight model is finite."""
+
+    def __init__(self, embed_dim, context_length, vocab_size, transformer_width, transformer_heads, transformer_layers):
+        super().__init__()
+        self.context_length = context_length
+        self.transformer = Transformer(transformer_width, transformer_layers)
+        self.heads = transformer_heads
+        self.vocab_size = vocab_size
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(context_length, transformer_width))
+        self.ln_final = LayerNorm(transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        nn.init.normal_(self.text_projection, std=transformer_width ** -0.5)
+
+
+class TextPromptLearner(_Params):
+    """VitaCLIP_text_encoder.py:174-308, plain (non-KAPT) class-specific-context path."""
+
+    def __init__(self, classnames, text_model, num_prompts, prompts_init="", CSC=False, ctx_pos="end", **_unused):
+        super().__init__()
+        if prompts_init != "":
+            raise NotImplementedError(
+                "knowledge-aware prompts (text_prompt_init != '') need the KEPLER files under ./data/ke_* "
+                "(/root/reference/training/kapt_head.py:60-61); not part of the accelerated path (DESIGN.md)")
+        if not CSC:
+            # upstream: a generic (n_ctx, dim) ctx is unsqueezed to (n_ctx,1,dim) and cannot be
+            # concatenated (text_encoder.py:317,325-332) -> only CSC=True works there either.
+            raise NotImplementedError("text_prompt_CSC=False is broken in the reference (SURVEY.md §7.5); use CSC=True")
+        if ctx_pos != "end":
+            raise NotImplementedError(f"Unsupported class token position: {ctx_pos}")
+        n_cls, n_ctx = len(classnames), num_prompts
+        ctx_dim = text_model.ln_final.weight.shape[0]
+        ctx = torch.empty(n_cls, n_ctx, ctx_dim)
+        nn.init.normal_(ctx, std=0.02)
+        self.ctx = nn.Parameter(ctx)
+        texts = prompt_texts(classnames, n_ctx)
+        # list of (n_kv=1, 77) int tensors, one per class, like upstream (:266-270)
+        self.tokenized_prompts = [torch.from_numpy(tokenize(t, text_model.context_length)) for t in texts]
+        assert max(int((tp == 49407).nonzero()[:, -1].max()) for tp in self.tokenized_prompts) <= 77, \
+            "The tokenized prompt is too long"
+        self.n_cls, self.n_ctx = n_cls, n_ctx
+        self.class_token_position = ctx_pos
+        self.knowledge_aware_prompt = False
+
+
+# ---------------------------------------------------------------------------------------------
+class VitaCLIP(nn.Module):
+
+    def __init__(
+        self,
+        backbone_path: str = '',
+        input_size: Tuple[int, int] = (224, 224),
+        num_frames: int = 16,
+        use_fp16: bool = False,
+        cls_type: str = 'updrs',
+        num_classes: int = 4,
+        feature_dim: int = 768,
+        patch_size: Tuple[int, int] = (16, 16),
+        num_heads: int = 12,
+        num_layers: int = 12,
+        mlp_factor: float = 4.0,
+        embed_dim: int = 512,
+        use_summary_token: bool = False,
+        use_local_prompts: bool = False,
+        use_global_prompts: bool = False,
+        num_global_prompts: int = 8,
+        use_text_prompt_learning: bool = False,
+        text_context_length: int = 77,
+        text_vocab_size: int = 49408,
+        text_transformer_width: int = 512,
+        text_transformer_heads: int = 8,
+        text_transformer_layers: int = 12,
+        text_num_prompts: int = 8,
+        text_prompt_pos: str = 'end',
+        text_prompt_init: str = '',
+        text_prompt_CSC: bool = False,
+        text_prompt_classes_path: str = '',
+        knowledge_version: List[str] = ['v0'],
+        use_descriptor: bool = False,
+        token_wise_mlp: bool = False,
+        zeroshot_evaluation: bool = False,
+        zeroshot_text_features_path: str = '',
+        use_support_memory: bool = False,
+        detach_features: bool = False,
+        memory_batch_size: int = 64,
+        add_nte: bool = False,
+        use_sigmoid_loss: bool = False,
+        *,
+        operand_dtype: str = None,
+    ):
+        super().__init__()
+        if not (use_summary_token and use_local_prompts and use_global_prompts):
+            # upstream's non-global-prompt branch assigns the block's tuple to x and leaves
+            # `summary` undefined (VitaCLIP_vision_encoder.py:123-124,129): it cannot run.
+            raise NotImplementedError("only use_summary_token=use_local_prompts=use_global_prompts=True is a "
+                                      "working configuration of the reference (SURVEY.md §7.5)")
+        if isinstance(input_size, int):
+            input_size = (input_size, input_size)
+        if isinstance(patch_size, int):
+            patch_size = (patch_size, patch_size)
+        self.fp16 = use_fp16
+        self.num_frames = num_frames
+        self.num_classes = num_classes
+        self.text_context_length = text_context_length
+        self.text_transformer_width = text_transformer_width
+        self.use_summary_token = use_summary_token
+        self.use_sigmoid_loss = use_sigmoid_loss
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.logit_bias = None
+        self.zeroshot_evaluation = zeroshot_evaluation
+        if self.zeroshot_evaluation:
+            self.text_features = torch.load(zeroshot_text_features_path, map_location='cpu',
+                                            weights_only=True)['text_features']
+        self.visual = CLIPVisionEncoder(input_size, num_frames, feature_dim, patch_size, num_heads, num_layers,
+                                        mlp_factor, embed_dim, num_global_prompts)
+        self.use_text_prompt_learning = use_text_prompt_learning
+        if self.use_text_prompt_learning:
+            self.textual = CLIPTextEncoder(embed_dim, text_context_length, text_vocab_size, text_transformer_width,
+                                           text_transformer_heads, text_transformer_layers)
+        if backbone_path:
+            ckpt = torch.load(backbone_path, map_location='cpu', weights_only=True)
+            self.load_state_dict(ckpt, strict=False)
+
+        self.use_support_memory = use_support_memory
+        self.memoty_batch_size = memory_batch_size
+        self.detach_features = detach_features
+        self.add_nte = add_nte
+        if self.add_nte:
+            self.sum_proj = nn.Linear(feature_dim, embed_dim)
+            self.logit_scale_vm = nn.Parameter(torch.ones([]) * (np.log(10.) if use_sigmoid_loss else 100.))
+        if self.use_support_memory:
+            def _mlp():
+                return nn.Sequential(nn.Linear(embed_dim, embed_dim // 4), nn.Tanh(), nn.Linear(embed_dim // 4, embed_dim // 8))
+            self.tf_project = _mlp()
+            self.memory_project = nn.ModuleList([_mlp() for _ in range(num_classes)])
+            if use_sigmoid_loss:
+                self.logit_scale_mt = nn.Parameter(torch.ones([]) * np.log(10.))
+                self.logit_bias_mt = nn.Parameter(torch.ones([]) * -10.)
+            else:
+                self.logit_scale_mt = nn.Parameter(torch.ones([]) * 100.)
+                self.logit_bias_mt = None
+        if use_sigmoid_loss:
+            self.logit_scale = nn.Parameter(torch.ones([]) * np.log(np.log(10.)))
+            self.logit_bias = nn.Parameter(torch.ones([]) * -10.)
+
+        if self.use_text_prompt_learning:
+            classes = read_class_names(text_prompt_classes_path)
+            self.prompt_learner = TextPromptLearner(classnames=classes, text_model=self.textual,
+                                                    num_prompts=text_num_prompts, prompts_init=text_prompt_init,
+                                                    CSC=text_prompt_CSC, ctx_pos=text_prompt_pos)
+            self.tokenized_prompts = self.prompt_learner.tokenized_prompts
+
+        # freeze (VitaCLIP_model.py:222-239)
+        for name, param in self.visual.named_parameters():
+            if not ('summary' in name or 'local' in name or 'global' in name or 'time_embed' in name):
+                param.requires_grad = False
+        if hasattr(self, "textual"):
+            for param in self.textual.named_parameters():
+                param[1].requires_grad = False
+
+        # ---- HIP-path state (not part of the reference surface)
+        operand_dtype = operand_dtype or os.environ.get("GAVA_PREC", "fp16")
+        self.prec = hip.PREC_NAMES[operand_dtype]
+        self.gather_across_ranks = True     # RCCL all-gather of clip embeddings when world_size > 1
+        self.debug_taps = False             # keep per-layer CLS rows of the last forward
+        self._shape = dict(size=input_size[0], P=patch_size[0], D=feature_dim, H=num_heads, layers=num_layers,
+                           F=round(mlp_factor * feature_dim), E=embed_dim, G=num_global_prompts,
+                           W=text_transformer_width, TH=text_transformer_heads, TL=text_transformer_layers,
+                           L=text_context_length, n_ctx=text_num_prompts)
+        self._packed = None
+        self._packed_key = None
+        self._ws = {}
+        self.last = {}
+
+    # ---- weight packing -----------------------------------------------------------------------
+    def set_operand_dtype(self, name: str):
+        self.prec = hip.PREC_NAMES[name]
+        self._packed = None
+
+    def _pack_key(self):
+        ps = list(self.parameters())
+        return (self.prec, ps[0].device, ps[0].data_ptr(), sum(p._version for p in ps))
+
+    def _h16(self, t):
+        return hip.convert_h16(t.detach().float(), self.prec)
+
+    def _f32(self, t):
+        return t.detach().float().contiguous()
+
+    def _pack(self):
+        key = self._pack_key()
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        sh, v = self._shape, self.visual
+        keep = []  # tensors referenced by raw pointers in the structs
+
+        def K(t):
+            keep.append(t)
+            return C.c_void_p(t.data_ptr())
+
+        Kp = (3 * sh["P"] ** 2 + 63) // 64 * 64
+        wpatch = v.patch_embed.proj.weight.detach().float().reshape(sh["D"], -1)
+        if Kp != wpatch.shape[1]:
+            wpatch = F.pad(wpatch, (0, Kp - wpatch.shape[1]))
+        vis = dict(w_patch=K(self._h16(wpatch)), b_patch=K(self._f32(v.patch_embed.proj.bias)),
+                   cls_token=K(self._f32(v.cls_token)), pos_embed=K(self._f32(v.pos_embed)),
+                   lnpre_g=K(self._f32(v.ln_pre.weight)), lnpre_b=K(self._f32(v.ln_pre.bias)),
+                   lnpost_g=K(self._f32(v.ln_post.weight)), lnpost_b=K(self._f32(v.ln_post.bias)),
+                   w_proj=K(self._h16(v.proj.detach().float().t().contiguous())))
+        layers = (hip.VisionLayer * sh["layers"])()
+        for i, blk in enumerate(v.blocks):
+            a, s = blk.attn, blk.summary_attn_layer
+            L = layers[i]
+            L.w_qkv = K(self._h16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)))
+            L.b_qkv = K(self._f32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)))
+            L.w_out, L.b_out = K(self._h16(a.out_proj.weight)), K(self._f32(a.out_proj.bias))
+            L.w_fc1, L.b_fc1 = K(self._h16(blk.mlp.fc1.weight)), K(self._f32(blk.mlp.fc1.bias))
+            L.w_fc2, L.b_fc2 = K(self._h16(blk.mlp.fc2.weight)), K(self._f32(blk.mlp.fc2.bias))
+            L.ln1_g, L.ln1_b = K(self._f32(blk.norm1.weight)), K(self._f32(blk.norm1.bias))
+            L.ln2_g, L.ln2_b = K(self._f32(blk.norm2.weight)), K(self._f32(blk.norm2.bias))
+            L.w_cls, L.b_cls = K(self._h16(blk.cls_proj.weight)), K(self._f32(blk.cls_proj.bias))
+            L.sln_g, L.sln_b = K(self._f32(blk.summary_ln.weight)), K(self._f32(blk.summary_ln.bias))
+            L.w_sqkv = K(self._h16(torch.cat([s.q_proj.weight, s.k_proj.weight, s.v_proj.weight], 0)))
+            L.b_sqkv = K(self._f32(torch.cat([s.q_proj.bias, s.k_proj.bias, s.v_proj.bias], 0)))
+            L.w_sout, L.b_sout = K(self._h16(s.out_proj.weight)), K(self._f32(s.out_proj.bias))
+            L.local_prompts = K(self._f32(blk.local_prompts[0]))
+            L.global_prompts = K(self._f32(v.global_prompts[i]))
+        packed = dict(vis=vis, vis_layers=layers, keep=keep)
+        if self.use_text_prompt_learning:
+            t = self.textual
+            tlayers = (hip.TextLayer * sh["TL"])()
+            for i, blk in enumerate(t.transformer.resblocks):
+                L = tlayers[i]
+                L.w_qkv, L.b_qkv = K(self._h16(blk.attn.in_proj_weight)), K(self._f32(blk.attn.in_proj_bias))
+                L.w_out, L.b_out = K(self._h16(blk.attn.out_proj.weight)), K(self._f32(blk.attn.out_proj.bias))
+                L.w_fc, L.b_fc = K(self._h16(blk.mlp.c_fc.weight)), K(self._f32(blk.mlp.c_fc.bias))
+                L.w_proj, L.b_proj = K(self._h16(blk.mlp.c_proj.weight)), K(self._f32(blk.mlp.c_proj.bias))
+                L.ln1_g, L.ln1_b = K(self._f32(blk.ln_1.weight)), K(self._f32(blk.ln_1.bias))
+                L.ln2_g, L.ln2_b = K(self._f32(blk.ln_2.weight)), K(self._f32(blk.ln_2.bias))
+            dev = t.token_embedding.weight.device
+            tok = torch.cat(self.tokenized_prompts).to(device=dev, dtype=torch.int32).contiguous()
+            eot_col = (tok == t.vocab_size - 1).nonzero()[:, -1]
+            assert eot_col.numel() == tok.shape[0], "every prompt must contain exactly one EOT token"
+            eot = (torch.arange(tok.shape[0], device=dev) * sh["L"] + eot_col).to(torch.int32).contiguous()
+            packed.update(txt=dict(token_embedding=K(self._f32(t.token_embedding.weight)),
+                                   positional_embedding=K(self._f32(t.positional_embedding)),
+                                   lnf_g=K(self._f32(t.ln_final.weight)), lnf_b=K(self._f32(t.ln_final.bias)),
+                                   w_tproj=K(self._h16(t.text_projection.detach().float().t().contiguous()))),
+                          txt_layers=tlayers, tokens=tok, eot=eot)
+        self._packed, self._packed_key = packed, key
+        return packed
+
+    def _workspace(self, tag, nbytes, device):
+        ws = self._ws.get(tag)
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._ws[tag] = ws
+        return ws
+
+    # ---- encoders -----------------------------------------------------------------------------
+    def encode_video(self, x):
+        """CLIPVisionEncoder.forward on the HIP path -> (cls_x (B,E), summary (B,D)), fp32."""
+        if not x.is_cuda:
+            raise hip.GavaError("VitaCLIP (gava_clip_amd) runs on the HIP device only: move the model and the "
+                                "input with .cuda(); there is no CPU fallback")
+        lib = hip.load()
+        pk, sh = self._pack(), self._shape
+        B, Cc, T, Hh, Ww = x.shape
+        assert Cc == 3 and Hh == sh["size"] and Ww == sh["size"], "input must be (B,3,T,size,size)"
+        x = x.detach().float().contiguous()
+        te = self.visual.time_embed.detach().float()
+        if T != te.size(0):  # VitaCLIP_vision_encoder.py:91-95
+            te = F.interpolate(te.unsqueeze(0).transpose(1, 2), size=(T), mode='nearest').transpose(1, 2).squeeze(0)
+        te = te.contiguous()
+        m = hip.VisionModel()
+        m.B, m.T_in, m.T_model = B, T, self.num_frames
+        for k in ("size", "P", "D", "H", "layers", "F", "E", "G"):
+            setattr(m, k, sh[k])
+        m.prec = self.prec
+        for k, val in pk["vis"].items():
+            setattr(m, k, val)
+        m.time_embed = C.c_void_p(te.data_ptr())
+        m.layer = C.cast(pk["vis_layers"], C.POINTER(hip.VisionLayer))
+        nbytes = lib.gava_vision_workspace_bytes(C.byref(m))
+        if nbytes == 0:
+            raise hip.GavaError(f"unsupported vision shape: B={B} T={T} num_frames={self.num_frames} {sh}")
+        ws = self._workspace("vision", nbytes, x.device)
+        cls_x = torch.empty(B, sh["E"], dtype=torch.float32, device=x.device)
+        summary = torch.empty(B * T // self.num_frames, sh["D"], dtype=torch.float32, device=x.device)
+        dbg = torch.empty(sh["layers"], B * T, sh["D"], dtype=torch.float32, device=x.device) if self.debug_taps else None
+        hip.check(lib.gava_vision_forward(C.byref(m), hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), hip.ptr(dbg),
+                                          hip.ptr(ws), ws.numel(), hip.stream_ptr()), "gava_vision_forward")
+        self.last["cls_rows"] = dbg
+        return cls_x, summary
+
+    def encode_text(self):
+        """prompt_learner() + textual(...) for all classes in one batch -> (C, E) fp32."""
+        lib = hip.load()
+        pk, sh = self._pack(), self._shape
+        tok = pk["tokens"]
+        n = tok.shape[0]
+        m = hip.TextModel()
+        m.n_prompts, m.L, m.W, m.H, m.layers = n, sh["L"], sh["W"], sh["TH"], sh["TL"]
+        m.E, m.n_ctx, m.prec = sh["E"], sh["n_ctx"], self.prec
+        for k, val in pk["txt"].items():
+            setattr(m, k, val)
+        m.layer = C.cast(pk["txt_layers"], C.POINTER(hip.TextLayer))
+        nbytes = lib.gava_text_workspace_bytes(C.byref(m))
+        if nbytes == 0:
+            raise hip.GavaError(f"unsupported text shape: {sh}")
+        ws = self._workspace("text", nbytes, tok.device)
+        ctx = self.prompt_learner.ctx.detach().float().contiguous()
+        out = torch.empty(n, sh["E"], dtype=torch.float32, device=tok.device)
+        hip.check(lib.gava_text_forward(C.byref(m), hip.ptr(tok), hip.ptr(ctx), hip.ptr(pk["eot"]), hip.ptr(out),
+                                        hip.ptr(ws), ws.numel(), hip.stream_ptr()), "gava_text_forward")
+        return out
+
+    def _gather(self, feats):
+        """RCCL all-gather over xGMI of the per-clip embeddings (north_star): each rank
+        holds whole clips, every rank ends with the embeddings (and logits) of the global batch."""
+        import torch.distributed as dist
+        if not (self.gather_across_ranks and dist.is_available() and dist.is_initialized()
+                and dist.get_world_size() > 1):
+            return feats
+        out = torch.empty(dist.get_world_size() * feats.shape[0], feats.shape[1], dtype=feats.dtype, device=feats.device)
+        dist.all_gather_into_tensor(out, feats.contiguous())
+        return out
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, memory=None, video_nte=None, desc_wise=False):
+        lib = hip.load()
+        B, Cc, T, Hh, Ww = x.size()
+        sh = self._shape
+        cls_x, summary = self.encode_video(x)
+        video = self._gather(cls_x)
+        if self.use_text_prompt_learning:
+            if desc_wise:
+                assert self.training == False
+            text = self.encode_text()
+        else:
+            text = self.text_features.to(device=x.device, dtype=torch.float32).contiguous()
+        Bg, Cn = video.shape[0], text.shape[0]
+        logits = torch.empty(Bg, Cn, dtype=torch.float32, device=x.device)
+        tfeat = torch.empty(Cn, sh["E"], dtype=torch.float32, device=x.device)
+        vnorm = torch.empty(Bg, sh["E"], dtype=torch.float32, device=x.device)
+        ls = self.logit_scale.detach().float().reshape(1)
+        lb = self.logit_bias.detach().float().reshape(1) if self.logit_bias is not None else None
+        hip.check(lib.gava_similarity_head(hip.ptr(video), hip.ptr(text), hip.ptr(ls), hip.ptr(lb), Bg, Cn, 1,
+                                           sh["E"], hip.ptr(logits), hip.ptr(tfeat), hip.ptr(vnorm), hip.stream_ptr()),
+                  "gava_similarity_head")
+        self.last.update(video_features=vnorm, summary=summary)
+        if self.use_text_prompt_learning:
+            self.text_features = tfeat            # VitaCLIP_model.py:293
+        if desc_wise and self.use_text_prompt_learning:
+            logits = [logits[:, i:i + 1] for i in range(Cn)]   # list of (B, n_kv=1), :265-276
+
+        # auxiliary heads: inactive at every accelerated configuration; kept as PyTorch glue on the
+        # device so that callers passing video_nte / memory still get the reference's outputs.
+        if self.add_nte and video_nte is not None:              # VitaCLIP_model.py:311-345
+            sp = self.sum_proj(summary)
+            sp = sp / sp.norm(dim=-1, keepdim=True)
+            with torch.no_grad():
+                valid_idx = ((video_nte.sum(dim=-1).sum(dim=-1)) != 0).float()
+                valid_mat = valid_idx.unsqueeze(1) * valid_idx.unsqueeze(0)
+            video_nte = video_nte / video_nte.norm(dim=-1, keepdim=True)
+            similarity = torch.bmm(sp.unsqueeze(0).expand(NUM_COMB, -1, -1), video_nte.permute(1, 2, 0)).mean(0)
+            logits_mat = self.logit_scale_vm * (similarity * valid_mat)
+            logits_vm = F.log_softmax(logits_mat, dim=-1) + F.log_softmax(logits_mat, dim=-2)
+        else:
+            logits_vm = None
+        if self.use_support_memory and memory is not None:      # VitaCLIP_model.py:347-398
+            text_features = self.text_features.detach() if self.detach_features else self.text_features
+            memory = memory.mean(dim=1)
+            logits_mt = torch.empty(memory.size(0), 0).to(memory.device)
+            for cid, mproj in enumerate(self.memory_project):
+                tf = self.tf_project(text_features[cid])
+                tf = tf / tf.norm(dim=-1, keepdim=True)
+                memo = mproj(memory)
+                memo = memo / memo.norm(dim=-1, keepdim=True)
+                logits_mt = torch.concat([logits_mt, (self.logit_scale_mt * memo @ tf.t()).unsqueeze(-1)], dim=1)
+            logits_mt = F.log_softmax(logits_mt, dim=-1)
+            if self.logit_bias_mt is not None:
+                logits_mt += self.logit_bias_mt
+        else:
+            logits_mt = None
+        return logits, logits_mt, logits_vm

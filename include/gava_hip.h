@@ -1,0 +1,179 @@
+/* gava_hip.h — C ABI of libgava_hip.so: the MI355X (gfx950) implementation of the GaVA-CLIP
+ * video-frame forward path.
+ *
+ * The reference (lisqzqng/GaVA-CLIP) is pure PyTorch and has no FFI or operator registry; its
+ * boundary for this path is the Python class VitaCLIP(nn.Module)
+ * (training/VitaCLIP_model.py:22-401).  Each entry point below replaces the stock PyTorch ops
+ * of one stretch of that forward; the citation says which.  The host-side mirror
+ * (gava_clip_amd/model.py) binds them with ctypes, see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; nothing is allocated, freed or
+ *     synchronised inside a call; all work is enqueued on `stream` (a hipStream_t).
+ *   - return value: 0 on success, negative GAVA_E* on a rejected call (nothing launched).
+ *   - "h16" = 16-bit MFMA operand storage, fp16 or bf16 as selected by `prec`
+ *     (GAVA_PREC_*).  Accumulators, LayerNorm, softmax, residual stream and the
+ *     similarity head are always fp32.
+ *   - weights are [out_features][in_features] row-major (nn.Linear layout).
+ */
+#ifndef GAVA_HIP_H
+#define GAVA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAVA_OK 0
+#define GAVA_EINVAL (-1)   /* shape/alignment the kernels do not support */
+#define GAVA_EWORKSPACE (-2) /* workspace too small */
+#define GAVA_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after a launch */
+
+#define GAVA_PREC_F16 0
+#define GAVA_PREC_BF16 1
+
+/* GEMM epilogues */
+#define GAVA_EPI_H16 0        /* out16 = (acc + bias) * (col < scale_cols ? scale : 1)        */
+#define GAVA_EPI_H16_QGELU 1  /* out16 = quickgelu(acc + bias), x*sigmoid(1.702x)              */
+#define GAVA_EPI_F32 2        /* out32 = acc + bias (+ resid32, may alias out32)               */
+#define GAVA_EPI_F32_PATCH 3  /* patch-embed: row remap + pos/time embedding (see below)       */
+
+typedef void* gava_stream_t;
+
+int gava_abi_version(void);
+
+/* C[M,N] = A[M,K] · W[N,K]^T with a fused epilogue.  Replaces nn.Linear / the conv-as-GEMM of
+ * ImagePatchEmbed2D (VitaCLIP_vision_encoder_utils.py:66,79,110-115,215-219;
+ * VitaCLIP_text_encoder.py:73-77 and the projections inside nn.MultiheadAttention :71).
+ * Requirements: N % 128 == 0, K % 64 == 0, lda/ldw multiples of 8 elements, 16-byte aligned
+ * pointers.  M is arbitrary. */
+typedef struct {
+  const void* A; int64_t lda;       /* h16 [M][lda]                                    */
+  const void* W; int64_t ldw;       /* h16 [N][ldw]                                    */
+  const float* bias;                /* [N] or NULL                                     */
+  void* out; int64_t ldo;           /* h16 or fp32 [rows][ldo]                         */
+  const float* resid; int64_t ldr;  /* EPI_F32: optional fp32 residual, may alias out  */
+  int M, N, K;
+  int epilogue;                     /* GAVA_EPI_*                                      */
+  int prec;                         /* GAVA_PREC_*                                     */
+  int scale_cols; float scale;      /* EPI_H16: columns [0,scale_cols) are multiplied  */
+  /* EPI_F32_PATCH: GEMM row m = frame*n_patches + p is written to output row
+   * frame*(n_patches+1) + 1 + p with + pos[(1+p)][:] + time[(frame % T)][:]
+   * (VitaCLIP_vision_encoder.py:108-111,86-100). */
+  const float* pos; const float* time; int n_patches; int T;
+} gava_gemm_args;
+int gava_gemm(const gava_gemm_args* a, gava_stream_t stream);
+
+/* Row LayerNorm (eps 1e-5, affine) fp32 -> h16 and/or fp32; one wave per row.  Replaces
+ * LayerNorm (VitaCLIP_vision_encoder_utils.py:22-28, VitaCLIP_text_encoder.py:19-25).
+ * gamma == NULL means "no normalisation": the row is only converted (used to feed cls_proj,
+ * utils:164-165).  in_row_index (optional, int32[rows]) gathers input rows. D % 4 == 0, D <= 1024. */
+typedef struct {
+  const float* in; int64_t in_stride; const int32_t* in_row_index;
+  const float* gamma; const float* beta;
+  void* out16; int64_t out16_stride;     /* may be NULL */
+  float* out32; int64_t out32_stride;    /* may be NULL; may alias in */
+  int rows, D, prec;
+} gava_layernorm_args;
+int gava_layernorm(const gava_layernorm_args* a, gava_stream_t stream);
+
+/* Fused softmax(QK^T)V for head dim 64, whole key row resident in LDS (single-pass softmax).
+ * Replaces Attention.forward's einsum/softmax/einsum (VitaCLIP_vision_encoder_utils.py:71-77)
+ * and the scaled-dot-product inside nn.MultiheadAttention (VitaCLIP_text_encoder.py:81-83).
+ * Q must already carry the 1/sqrt(64) factor.  Problem (n, h): queries are rows
+ * n*n_q .. n*n_q+n_q-1 of q; keys/values are n_kmain rows n*n_kmain.. of k/v followed by
+ * "side" rows taken from side_k/side_v (vision prompt tokens, see gava_vision_forward):
+ *   n_g rows [0,n_g)                            shared by every problem   (global prompts)
+ *   T   rows n_g + (n / T)*T + [0,T)            shared by the T frames of a clip (local prompts)
+ *   1   row  n_g + batch + n                    per problem               (summary token)
+ * With n_side == 0 there are no side rows.  causal: key j is visible to query i iff j <= i.
+ * Total keys <= 320. */
+typedef struct {
+  const void* q; const void* k; const void* v; int64_t ld_qkv;  /* h16, element strides */
+  const void* side_k; const void* side_v; int64_t ld_side;
+  void* out; int64_t ld_out;                                     /* h16 [batch*n_q][ld_out] */
+  int batch, heads, n_q, n_kmain;
+  int n_g, T, has_summary;                                       /* side-row structure      */
+  int causal, prec;
+} gava_attention_args;
+int gava_attention(const gava_attention_args* a, gava_stream_t stream);
+
+/* ---- fused drivers ---------------------------------------------------------------------- */
+
+typedef struct {                 /* one TransformerEncoderLayer, utils:93-203 */
+  const void* w_qkv; const float* b_qkv;   /* [3D][D]: q_proj;k_proj;v_proj stacked          */
+  const void* w_out; const float* b_out;   /* [D][D]                                         */
+  const void* w_fc1; const float* b_fc1;   /* [F][D]                                         */
+  const void* w_fc2; const float* b_fc2;   /* [D][F]                                         */
+  const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
+  const void* w_cls; const float* b_cls;   /* cls_proj [D][D]                                */
+  const float* sln_g; const float* sln_b;  /* summary_ln                                     */
+  const void* w_sqkv; const float* b_sqkv; /* summary_attn_layer q;k;v stacked [3D][D]       */
+  const void* w_sout; const float* b_sout;
+  const float* local_prompts;              /* [T][D] fp32                                    */
+  const float* global_prompts;             /* [G][D] fp32 (row i of visual.global_prompts)   */
+} gava_vision_layer;
+
+typedef struct {
+  int B, T_in, T_model;          /* clips, frames per clip in x, num_frames of the model      */
+  int size, P, D, H, layers, F, E, G;
+  int prec;
+  const void* w_patch; const float* b_patch;   /* [D][Kp] h16, Kp = 3*P*P rounded up to 64   */
+  const float* cls_token; const float* pos_embed; const float* time_embed; /* time: [T_in][D] */
+  const float* lnpre_g; const float* lnpre_b; const float* lnpost_g; const float* lnpost_b;
+  const void* w_proj;                          /* visual.proj transposed: [E][D] h16          */
+  const gava_vision_layer* layer;              /* host array [layers]                         */
+} gava_vision_model;
+
+/* CLIPVisionEncoder.forward (VitaCLIP_vision_encoder.py:102-132).
+ * x: fp32 (B,3,T_in,size,size) contiguous.  cls_x: fp32 [B][E] (un-normalised, :126-128),
+ * summary: fp32 [B][D] (:129-130).  debug_cls (optional): fp32 [layers][B*T_in][D] receives the
+ * CLS row of every frame after each block. */
+size_t gava_vision_workspace_bytes(const gava_vision_model* m);
+int gava_vision_forward(const gava_vision_model* m, const float* x, float* cls_x, float* summary,
+                        float* debug_cls, void* workspace, size_t workspace_bytes,
+                        gava_stream_t stream);
+
+typedef struct {                 /* ResidualAttentionBlock, VitaCLIP_text_encoder.py:67-88 */
+  const void* w_qkv; const float* b_qkv;   /* attn.in_proj_weight [3W][W]                    */
+  const void* w_out; const float* b_out;
+  const void* w_fc; const float* b_fc;     /* mlp.c_fc [4W][W]                               */
+  const void* w_proj; const float* b_proj; /* mlp.c_proj [W][4W]                             */
+  const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
+} gava_text_layer;
+
+typedef struct {
+  int n_prompts, L, W, H, layers, E, n_ctx, prec;
+  const float* token_embedding;            /* [vocab][W] fp32                                */
+  const float* positional_embedding;       /* [L][W]                                         */
+  const float* lnf_g; const float* lnf_b;
+  const void* w_tproj;                     /* text_projection transposed [E][W] h16          */
+  const gava_text_layer* layer;            /* host array [layers]                            */
+} gava_text_model;
+
+/* TextPromptLearner.forward + CLIPTextEncoder.forward for all prompts in one batch
+ * (VitaCLIP_text_encoder.py:310-332,154-171; the per-class Python loop of
+ * VitaCLIP_model.py:282-285).  tokens: int32 [n_prompts][L]; ctx: fp32 [n_prompts][n_ctx][W];
+ * eot_index: int32 [n_prompts], FLAT row n*L + column of the token vocab-1 (text_encoder.py:169).
+ * out: fp32 [n_prompts][E]. */
+size_t gava_text_workspace_bytes(const gava_text_model* m);
+int gava_text_forward(const gava_text_model* m, const int32_t* tokens, const float* ctx,
+                      const int32_t* eot_index, float* out, void* workspace,
+                      size_t workspace_bytes, gava_stream_t stream);
+
+/* Similarity head (VitaCLIP_model.py:255,287-293): L2-normalise video [B][E] and text
+ * [C*n_kv][E] rows (no epsilon), logits[b][c] = exp(logit_scale) * mean_k <v_b, t_{c,k}>
+ * (+ logit_bias if not NULL); text_features[c] = normalise(mean_k t_{c,k}).  All fp32.
+ * video_norm (optional) receives the normalised video features. */
+int gava_similarity_head(const float* video, const float* text, const float* logit_scale,
+                         const float* logit_bias, int B, int C, int n_kv, int E, float* logits,
+                         float* text_features, float* video_norm, gava_stream_t stream);
+
+/* fp32 -> h16 conversion of a contiguous array (weight packing at load time). */
+int gava_convert_h16(const float* in, void* out, size_t n, int prec, gava_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,35 @@
+"""Shared builders for the parity tests (synthetic weights, model construction)."""
+import os
+
+import numpy as np
+import torch
+
+from gava_clip_amd import synth
+from gava_clip_amd.config import VitaConfig
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLASSES_3 = os.path.join(REPO, "gava_clip_amd", "data", "classes", "updrs_3cls_classes.txt")
+CLASSES_400 = os.path.join(REPO, "gava_clip_amd", "data", "classes", "k400_classes.txt")
+
+
+def model_kwargs(cfg: VitaConfig, class_file=CLASSES_3):
+    """Constructor call of evaluation/evaluate.py:207-250 for a given shape."""
+    return dict(backbone_path="", input_size=(cfg.input_size, cfg.input_size), num_frames=cfg.num_frames,
+                feature_dim=cfg.feature_dim, patch_size=(cfg.patch_size, cfg.patch_size), num_heads=cfg.num_heads,
+                num_layers=cfg.num_layers, mlp_factor=cfg.mlp_factor, embed_dim=cfg.embed_dim,
+                use_summary_token=True, use_local_prompts=True, use_global_prompts=True,
+                num_global_prompts=cfg.num_global_prompts, use_text_prompt_learning=True,
+                text_context_length=cfg.text_context_length, text_vocab_size=cfg.text_vocab_size,
+                text_transformer_width=cfg.text_width, text_transformer_heads=cfg.text_heads,
+                text_transformer_layers=cfg.text_layers, text_num_prompts=cfg.text_num_prompts,
+                text_prompt_pos="end", text_prompt_init="", text_prompt_CSC=True,
+                text_prompt_classes_path=class_file)
+
+
+def synth_torch_state(cfg, n_cls, seed=0):
+    return {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg, n_cls, seed).items()}
+
+
+def rel_to_max(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / np.abs(b).max())

@@ -1,0 +1,184 @@
+"""GPU: every C-ABI kernel against a plain torch fp32 reference of the same op on the same
+16-bit-rounded operands (so the only differences are fp32 summation order and the final rounding)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gava_clip_amd import hip  # noqa: E402
+
+PRECS = [hip.PREC_F16, hip.PREC_BF16]
+EPS16 = {hip.PREC_F16: 2 ** -11, hip.PREC_BF16: 2 ** -8}
+
+
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    hip.load()
+    return torch.device("cuda:0")
+
+
+def rnd(shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (3, 128, 128), (1000, 384, 768), (257, 768, 3072)])
+def test_gemm_epilogues(prec, M, N, K):
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    A = rnd((M, K), 1.0, 1).to(d).to(dt)
+    W = rnd((N, K), K ** -0.5, 2).to(d).to(dt)
+    bias = rnd((N,), 0.5, 3).to(d)
+    ref = A.float() @ W.float().t() + bias
+    tol = 4 * EPS16[prec]
+    # H16 with column scaling
+    out = torch.zeros(M, N, dtype=dt, device=d)
+    hip.gemm(A, W, bias, out, epilogue=hip.EPI_H16, prec=prec, scale_cols=N // 2, scale=0.125)
+    r = ref.clone(); r[:, :N // 2] *= 0.125
+    assert torch.allclose(out.float(), r, rtol=tol, atol=tol * 2)
+    # quick-gelu
+    out = torch.zeros(M, N, dtype=dt, device=d)
+    hip.gemm(A, W, bias, out, epilogue=hip.EPI_H16_QGELU, prec=prec)
+    r = ref * torch.sigmoid(1.702 * ref)
+    assert torch.allclose(out.float(), r, rtol=tol, atol=tol * 2)
+    # fp32, no residual, no bias
+    out = torch.zeros(M, N, dtype=torch.float32, device=d)
+    hip.gemm(A, W, None, out, epilogue=hip.EPI_F32, prec=prec)
+    assert torch.allclose(out, ref - bias, rtol=1e-4, atol=1e-4)
+    # fp32 in-place residual
+    X = rnd((M, N), 1.0, 4).to(d)
+    X0 = X.clone()
+    hip.gemm(A, W, bias, X, epilogue=hip.EPI_F32, prec=prec, resid=X)
+    assert torch.allclose(X, X0 + ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_gemm_does_not_touch_rows_beyond_M(prec):
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    M, N, K = 130, 128, 64
+    A = rnd((M, K)).to(d).to(dt)
+    W = rnd((N, K)).to(d).to(dt)
+    out = torch.full((256, N), 7.0, dtype=torch.float32, device=d)
+    hip.gemm(A, W, None, out, epilogue=hip.EPI_F32, prec=prec, M=M)
+    assert torch.all(out[M:] == 7.0)
+    assert torch.allclose(out[:M], A.float() @ W.float().t(), rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_patch_epilogue_and_rejects():
+    d = dev()
+    prec = hip.PREC_F16
+    frames, n, T, D, K = 6, 16, 3, 128, 192
+    A = rnd((frames * n, K), 1.0, 5).to(d).half()
+    W = rnd((D, K), K ** -0.5, 6).to(d).half()
+    bias, pos, tim = rnd((D,), 1, 7).to(d), rnd((n + 1, D), 1, 8).to(d), rnd((T, D), 1, 9).to(d)
+    X = torch.zeros(frames * (n + 1), D, device=d)
+    hip.gemm(A, W, bias, X, epilogue=hip.EPI_F32_PATCH, prec=prec, pos=pos, time=tim, n_patches=n, T=T)
+    ref = (A.float() @ W.float().t() + bias).view(frames, n, D) + pos[1:].unsqueeze(0) \
+        + tim[torch.arange(frames, device=d) % T].unsqueeze(1)
+    Xv = X.view(frames, n + 1, D)
+    assert torch.allclose(Xv[:, 1:], ref, rtol=1e-4, atol=1e-4)
+    assert torch.all(Xv[:, 0] == 0)
+    with pytest.raises(hip.GavaError):   # N not a multiple of 128
+        hip.gemm(A, W[:100], None, torch.zeros(frames * n, 100, device=d), epilogue=hip.EPI_F32, prec=prec)
+    with pytest.raises(hip.GavaError):   # K not a multiple of 64
+        hip.gemm(A[:, :40].contiguous(), W[:, :40].contiguous(), None, X, epilogue=hip.EPI_F32, prec=prec)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("rows,D", [(5, 128), (1001, 768), (64, 1024), (33, 512)])
+def test_layernorm(prec, rows, D):
+    d = dev()
+    x = (rnd((rows, D), 3.0, 1) + 1.5).to(d)
+    g, b = (1 + rnd((D,), 0.1, 2)).to(d), rnd((D,), 0.1, 3).to(d)
+    ref = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-5)
+    o16 = torch.zeros(rows, D, dtype=hip.h16_dtype(prec), device=d)
+    o32 = torch.zeros(rows, D, device=d)
+    hip.layernorm(x, g, b, out16=o16, out32=o32, prec=prec)
+    assert torch.allclose(o32, ref, rtol=2e-6, atol=2e-6)
+    assert torch.equal(o16, o32.to(o16.dtype))
+    # in place fp32, strided gather of rows, cast-only
+    x2 = x.clone()
+    hip.layernorm(x2, g, b, out32=x2, prec=prec)
+    assert torch.allclose(x2, ref, rtol=2e-6, atol=2e-6)
+    idx = torch.arange(rows - 1, -1, -2, device=d, dtype=torch.int32)
+    o = torch.zeros(idx.numel(), D, device=d)
+    hip.layernorm(x, g, b, out32=o, prec=prec, rows=idx.numel(), row_index=idx)
+    assert torch.allclose(o, ref[idx.long()], rtol=2e-6, atol=2e-6)
+    c = torch.zeros(rows, D, dtype=hip.h16_dtype(prec), device=d)
+    hip.layernorm(x, None, None, out16=c, prec=prec)
+    assert torch.equal(c, x.to(c.dtype))
+
+
+def attn_ref(q, k, v, causal):
+    s = q.float() @ k.float().transpose(-1, -2)
+    if causal:
+        L = s.shape[-1]
+        s = s + torch.full((L, L), float("-inf"), device=s.device).triu_(1)
+    return s.softmax(-1) @ v.float()
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("batch,heads,L,causal", [(3, 8, 77, True), (5, 2, 8, False), (2, 12, 16, False),
+                                                  (4, 2, 197, False), (1, 16, 257, False)])
+def test_attention_plain_and_causal(prec, batch, heads, L, causal):
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    D = heads * 64
+    qkv = rnd((batch * L, 3 * D), 1.0, 11).to(d)
+    qkv[:, :D] *= 0.125
+    qkv = qkv.to(dt)
+    out = torch.zeros(batch * L, D, dtype=dt, device=d)
+    hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, batch=batch, heads=heads, n_q=L, n_kmain=L,
+                  prec=prec, causal=causal)
+    r = qkv.view(batch, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = attn_ref(r[0], r[1], r[2], causal).permute(0, 2, 1, 3).reshape(batch * L, D)
+    tol = 6 * EPS16[prec]
+    assert torch.allclose(out.float(), ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("B,T,G,n_main,heads", [(2, 4, 4, 17, 2), (2, 8, 8, 197, 12), (1, 16, 8, 197, 3)])
+def test_attention_with_side_rows(prec, B, T, G, n_main, heads):
+    """Vision layout: per-frame main tokens + [G global | T per-clip local | 1 per-frame summary]."""
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    D, BT = heads * 64, B * T
+    qkv = rnd((BT * n_main, 3 * D), 1.0, 21).to(d)
+    qkv[:, :D] *= 0.125
+    qkv = qkv.to(dt)
+    side = rnd((G + 2 * BT, 2 * D), 1.0, 22).to(d).to(dt)
+    out = torch.zeros(BT * n_main, D, dtype=dt, device=d)
+    hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, batch=BT, heads=heads, n_q=n_main,
+                  n_kmain=n_main, prec=prec, side_k=side[:, :D], side_v=side[:, D:], n_g=G, T=T, has_summary=True)
+    q = qkv[:, :D].view(BT, n_main, heads, 64)
+    k = qkv[:, D:2 * D].view(BT, n_main, D)
+    v = qkv[:, 2 * D:].view(BT, n_main, D)
+    ref = torch.zeros(BT, n_main, D, device=d)
+    for f in range(BT):
+        b = f // T
+        rows = torch.cat([torch.arange(G), G + b * T + torch.arange(T), torch.tensor([G + BT + f])]).to(d)
+        kf = torch.cat([k[f], side[rows, :D]], 0).view(-1, heads, 64).permute(1, 0, 2)
+        vf = torch.cat([v[f], side[rows, D:]], 0).view(-1, heads, 64).permute(1, 0, 2)
+        ref[f] = attn_ref(q[f].permute(1, 0, 2), kf, vf, False).permute(1, 0, 2).reshape(n_main, D)
+    tol = 6 * EPS16[prec]
+    assert torch.allclose(out.float(), ref.view(BT * n_main, D), rtol=tol, atol=tol)
+
+
+def test_similarity_head():
+    d = dev()
+    lib = hip.load()
+    B, Cn, E = 5, 3, 512
+    v, t = rnd((B, E), 2.0, 31).to(d), rnd((Cn, E), 3.0, 32).to(d)
+    ls = torch.tensor([math.log(1 / 0.07)], device=d)
+    logits, tf, vn = torch.zeros(B, Cn, device=d), torch.zeros(Cn, E, device=d), torch.zeros(B, E, device=d)
+    hip.check(lib.gava_similarity_head(hip.ptr(v), hip.ptr(t), hip.ptr(ls), None, B, Cn, 1, E, hip.ptr(logits),
+                                       hip.ptr(tf), hip.ptr(vn), hip.stream_ptr()), "head")
+    vr, tr = v / v.norm(dim=-1, keepdim=True), t / t.norm(dim=-1, keepdim=True)
+    assert torch.allclose(vn, vr, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(tf, tr / tr.norm(dim=-1, keepdim=True), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(logits, ls.exp() * vr @ tr.t(), rtol=1e-5, atol=1e-5)

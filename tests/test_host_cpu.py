@@ -1,0 +1,90 @@
+"""CPU: host-side logic and the C-ABI library surface (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from gava_clip_amd.config import TINY, VIT_B16_T8, VIT_L14_T32, param_shapes
+from helpers import REPO, CLASSES_3, CLASSES_400, model_kwargs, synth_torch_state
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from gava_clip_amd import hip
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    header = open(os.path.join(REPO, "include", "gava_hip.h")).read()
+    declared = set(re.findall(r"\b(gava_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(hip.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.gava_abi_version() == 1
+
+
+def test_ctypes_structs_match_header_sizes():
+    """sizeof of every ABI struct as the C compiler sees it == ctypes layout."""
+    import subprocess, tempfile
+    from gava_clip_amd import hip
+    names = {"gava_gemm_args": hip.GemmArgs, "gava_layernorm_args": hip.LayerNormArgs,
+             "gava_attention_args": hip.AttentionArgs, "gava_vision_layer": hip.VisionLayer,
+             "gava_vision_model": hip.VisionModel, "gava_text_layer": hip.TextLayer, "gava_text_model": hip.TextModel}
+    src = '#include <stdio.h>\n#include "gava_hip.h"\nint main(){' + "".join(
+        f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        out = subprocess.check_output([os.path.join(d, "s")]).decode().split()
+    sizes = dict(zip(out[::2], map(int, out[1::2])))
+    for n, cls in names.items():
+        assert ctypes.sizeof(cls) == sizes[n], n
+
+
+@pytest.mark.parametrize("cfg,cls_file,n_cls", [(TINY, CLASSES_3, 3), (VIT_B16_T8, CLASSES_400, 400)])
+def test_state_dict_keys_match_reference(cfg, cls_file, n_cls):
+    from gava_clip_amd import VitaCLIP
+    if cfg is VIT_B16_T8:
+        cfg = type(cfg)(num_layers=1, text_layers=1)  # same key pattern, fewer layers to allocate
+    m = VitaCLIP(**model_kwargs(cfg, cls_file))
+    want = param_shapes(cfg, n_cls)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == dict(want)
+    trainable = {n for n, p in m.named_parameters() if p.requires_grad}
+    assert "prompt_learner.ctx" in trainable and "logit_scale" in trainable
+    assert "visual.time_embed" in trainable and "visual.global_prompts" in trainable
+    assert all(("summary" in n or "local" in n or "global" in n or "time_embed" in n)
+               for n in trainable if n.startswith("visual."))
+    assert not any(n.startswith("textual.") for n in trainable)
+    assert len(m.tokenized_prompts) == n_cls and tuple(m.tokenized_prompts[0].shape) == (1, 77)
+
+
+def test_strict_load_and_no_cpu_fallback():
+    from gava_clip_amd import VitaCLIP
+    from gava_clip_amd.hip import GavaError
+    m = VitaCLIP(**model_kwargs(TINY))
+    m.load_state_dict(synth_torch_state(TINY, 3), strict=True)
+    m.eval()
+    with pytest.raises(GavaError):
+        with torch.no_grad():
+            m(torch.zeros(1, 3, TINY.num_frames, TINY.input_size, TINY.input_size))
+
+
+def test_broken_reference_configs_are_rejected():
+    from gava_clip_amd import VitaCLIP
+    kw = model_kwargs(TINY)
+    with pytest.raises(NotImplementedError):
+        VitaCLIP(**{**kw, "use_global_prompts": False})
+    with pytest.raises(NotImplementedError):
+        VitaCLIP(**{**kw, "text_prompt_CSC": False})
+    with pytest.raises(NotImplementedError):
+        VitaCLIP(**{**kw, "text_prompt_init": "cntn_split_uni_disc"})
+
+
+def test_flop_model_matches_survey():
+    from gava_clip_amd.flops import vision_flops_per_clip, text_flops_per_prompt, forward_flops
+    assert abs(vision_flops_per_clip(VIT_B16_T8) / 1e9 - 298.593) < 0.01
+    assert abs(text_flops_per_prompt(VIT_B16_T8) / 1e9 - 5.9595) < 0.001
+    assert abs(forward_flops(VIT_B16_T8, 64, 3) / 1e9 - 19127.8) < 0.5
+    assert abs(vision_flops_per_clip(VIT_L14_T32) / 1e9 - 5631.77) < 0.1
