@@ -22,7 +22,7 @@ struct AttnParams {
   const unsigned short* q; const unsigned short* k; const unsigned short* v; long ld;
   const unsigned short* sk; const unsigned short* sv; long lds;
   unsigned short* out; long ldo;
-  int batch, heads, n_q, n_kmain, n_g, T, has_summary, n_keys, causal;
+  int batch, heads, n_q, n_kmain, n_g, T, has_summary, n_keys, causal, split;
 };
 
 template <class P, int NKT>
@@ -129,10 +129,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     }
     if (qi < p.n_q) {
       unsigned short* op = p.out + ((long)n * p.n_q + qi) * p.ldo + h * 64 + 4 * fg;
+      const int Dm = p.heads * 64;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        *reinterpret_cast<uint2*>(op + dt * 16) =
-            pack4<P>(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+      for (int dt = 0; dt < 4; ++dt) {
+        if (p.split) {
+          uint2 hi, lo;
+          split4<P>(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv, hi, lo);
+          *reinterpret_cast<uint2*>(op + dt * 16) = hi;
+          *reinterpret_cast<uint2*>(op + dt * 16 + Dm) = lo;
+          *reinterpret_cast<uint2*>(op + dt * 16 + 2 * Dm) = hi;
+        } else {
+          *reinterpret_cast<uint2*>(op + dt * 16) =
+              pack4<P>(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+        }
+      }
     }
   }
 }
@@ -172,7 +182,8 @@ extern "C" int gava_attention(const gava_attention_args* a, gava_stream_t stream
   p.out = (unsigned short*)a->out; p.ldo = a->ld_out;
   p.batch = a->batch; p.heads = a->heads; p.n_q = a->n_q; p.n_kmain = a->n_kmain;
   p.n_g = a->n_g; p.T = n_side ? a->T : 1; p.has_summary = a->has_summary;
-  p.n_keys = a->n_kmain + n_side; p.causal = a->causal;
+  p.n_keys = a->n_kmain + n_side; p.causal = a->causal; p.split = a->split_out;
+  if (a->split_out && a->ld_out < 3 * (int64_t)a->heads * 64) return GAVA_EINVAL;
   if (p.n_keys > 320) return GAVA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (a->prec == GAVA_PREC_F16) return launch_attn<PrecF16>(p, s);

@@ -49,6 +49,15 @@ static __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d
   return r;
 }
 
+// hi/lo split of 4 values: hi = h16(v), lo = h16(v - hi)
+template <class P>
+static __device__ __forceinline__ void split4(float a, float b, float c, float d, uint2& hi, uint2& lo) {
+  const unsigned short ha = P::cvt(a), hb = P::cvt(b), hc = P::cvt(c), hd = P::cvt(d);
+  hi.x = (unsigned)ha | ((unsigned)hb << 16);
+  hi.y = (unsigned)hc | ((unsigned)hd << 16);
+  lo = pack4<P>(a - P::up(ha), b - P::up(hb), c - P::up(hc), d - P::up(hd));
+}
+
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

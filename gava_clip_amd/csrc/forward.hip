@@ -22,21 +22,21 @@ struct Carver {
   } while (0)
 
 int ln(const float* in, long in_stride, const int32_t* idx, const float* g, const float* b, void* o16, long o16s,
-       float* o32, long o32s, int rows, int D, int prec, gava_stream_t s) {
+       float* o32, long o32s, int rows, int D, int prec, gava_stream_t s, int split = 0) {
   gava_layernorm_args a{};
   a.in = in; a.in_stride = in_stride; a.in_row_index = idx; a.gamma = g; a.beta = b;
   a.out16 = o16; a.out16_stride = o16s; a.out32 = o32; a.out32_stride = o32s;
-  a.rows = rows; a.D = D; a.prec = prec;
+  a.rows = rows; a.D = D; a.prec = prec; a.split_out = split;
   return gava_layernorm(&a, s);
 }
 
 int gemm(const void* A, long lda, const void* W, long ldw, const float* bias, void* out, long ldo, int M, int N, int K,
          int epi, int prec, gava_stream_t s, const float* resid = nullptr, long ldr = 0, int scale_cols = 0,
-         float scale = 1.f) {
+         float scale = 1.f, int split_out = 0) {
   gava_gemm_args a{};
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo;
   a.resid = resid; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.prec = prec;
-  a.scale_cols = scale_cols; a.scale = scale;
+  a.scale_cols = scale_cols; a.scale = scale; a.split_out = split_out;
   return gava_gemm(&a, s);
 }
 
@@ -69,7 +69,7 @@ VisionWs carve_vision(const gava_vision_model* m, void* ws, size_t cap) {
   w.SUMM = (float*)c.take(BT * D * 4);
   w.SIDEn = c.take(SR * D * 2);
   w.SIDEKV = c.take(SR * 2 * D * 2);
-  w.CLSPOST = c.take(BT * D * 2);
+  w.CLSPOST = c.take(BT * 3 * D * 2);
   w.PROJ = (float*)c.take(BT * E * 4);
   w.total = (c.off + 255) & ~(size_t)255;
   return w;
@@ -161,8 +161,9 @@ extern "C" int gava_vision_forward(const gava_vision_model* m, const float* x, f
   }
 
   // ---- head (VitaCLIP_vision_encoder.py:126-130)
-  TRY(ln(w.X, fs, nullptr, m->lnpost_g, m->lnpost_b, w.CLSPOST, D, nullptr, 0, BT, D, pr, stream));
-  TRY(gemm(w.CLSPOST, D, m->w_proj, D, nullptr, w.PROJ, E, BT, E, D, GAVA_EPI_F32, pr, stream));
+  // split precision (3 MFMA passes): M = BT rows only, and its rounding lands directly on the output
+  TRY(ln(w.X, fs, nullptr, m->lnpost_g, m->lnpost_b, w.CLSPOST, 3 * D, nullptr, 0, BT, D, pr, stream, 1));
+  TRY(gemm(w.CLSPOST, 3 * D, m->w_proj, 3 * D, nullptr, w.PROJ, E, BT, E, 3 * D, GAVA_EPI_F32, pr, stream));
   TRY(gava::mean_rows(w.PROJ, cls_x, m->B, m->T_in, E, s));
   TRY(gava::mean_rows(w.SUMM, summary, BT / Tm, Tm, D, s));
   return GAVA_OK;
@@ -173,15 +174,15 @@ namespace {
 struct TextWs { float* X; void* Xn; void* QKV; void* MIX; void* HID; void* EOT16; size_t total; };
 
 TextWs carve_text(const gava_text_model* m, void* ws, size_t cap) {
-  const long R = (long)m->n_prompts * m->L, W = m->W;
+  const long R = (long)m->n_prompts * m->L, W = m->W, S = m->split ? 3 : 1;
   Carver c(ws, cap);
   TextWs w;
   w.X = (float*)c.take(R * W * 4);
-  w.Xn = c.take(R * W * 2);
+  w.Xn = c.take(R * S * W * 2);
   w.QKV = c.take(R * 3 * W * 2);
-  w.MIX = c.take(R * W * 2);
-  w.HID = c.take(R * 4 * W * 2);
-  w.EOT16 = c.take((long)m->n_prompts * W * 2);
+  w.MIX = c.take(R * S * W * 2);
+  w.HID = c.take(R * S * 4 * W * 2);
+  w.EOT16 = c.take((long)m->n_prompts * S * W * 2);
   w.total = (c.off + 255) & ~(size_t)255;
   return w;
 }
@@ -209,25 +210,27 @@ extern "C" int gava_text_forward(const gava_text_model* m, const int32_t* tokens
   if (w.total > workspace_bytes) return GAVA_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int R = m->n_prompts * m->L, W = m->W, pr = m->prec;
+  const int sp = m->split ? 1 : 0, S = sp ? 3 : 1;  // split precision: A rows are [hi|lo|hi], K' = 3K
   TRY(gava::text_embed(m->token_embedding, m->positional_embedding, ctx, tokens, w.X, m->n_prompts, m->L, W, m->n_ctx, s));
   for (int i = 0; i < m->layers; ++i) {
     const gava_text_layer& L = m->layer[i];
-    TRY(ln(w.X, W, nullptr, L.ln1_g, L.ln1_b, w.Xn, W, nullptr, 0, R, W, pr, stream));
-    TRY(gemm(w.Xn, W, L.w_qkv, W, L.b_qkv, w.QKV, 3 * W, R, 3 * W, W, GAVA_EPI_H16, pr, stream, nullptr, 0, W, 0.125f));
+    TRY(ln(w.X, W, nullptr, L.ln1_g, L.ln1_b, w.Xn, S * W, nullptr, 0, R, W, pr, stream, sp));
+    TRY(gemm(w.Xn, S * W, L.w_qkv, S * W, L.b_qkv, w.QKV, 3 * W, R, 3 * W, S * W, GAVA_EPI_H16, pr, stream, nullptr, 0, W, 0.125f));
     {
       gava_attention_args a{};
       const unsigned short* q = (const unsigned short*)w.QKV;
-      a.q = q; a.k = q + W; a.v = q + 2 * W; a.ld_qkv = 3 * W; a.out = w.MIX; a.ld_out = W;
+      a.q = q; a.k = q + W; a.v = q + 2 * W; a.ld_qkv = 3 * W; a.out = w.MIX; a.ld_out = S * W;
       a.batch = m->n_prompts; a.heads = m->H; a.n_q = m->L; a.n_kmain = m->L; a.causal = 1; a.prec = pr;
+      a.split_out = sp;
       TRY(gava_attention(&a, stream));
     }
-    TRY(gemm(w.MIX, W, L.w_out, W, L.b_out, w.X, W, R, W, W, GAVA_EPI_F32, pr, stream, w.X, W));
-    TRY(ln(w.X, W, nullptr, L.ln2_g, L.ln2_b, w.Xn, W, nullptr, 0, R, W, pr, stream));
-    TRY(gemm(w.Xn, W, L.w_fc, W, L.b_fc, w.HID, 4 * W, R, 4 * W, W, GAVA_EPI_H16_QGELU, pr, stream));
-    TRY(gemm(w.HID, 4 * W, L.w_proj, 4 * W, L.b_proj, w.X, W, R, W, 4 * W, GAVA_EPI_F32, pr, stream, w.X, W));
+    TRY(gemm(w.MIX, S * W, L.w_out, S * W, L.b_out, w.X, W, R, W, S * W, GAVA_EPI_F32, pr, stream, w.X, W));
+    TRY(ln(w.X, W, nullptr, L.ln2_g, L.ln2_b, w.Xn, S * W, nullptr, 0, R, W, pr, stream, sp));
+    TRY(gemm(w.Xn, S * W, L.w_fc, S * W, L.b_fc, w.HID, S * 4 * W, R, 4 * W, S * W, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, sp));
+    TRY(gemm(w.HID, S * 4 * W, L.w_proj, S * 4 * W, L.b_proj, w.X, W, R, W, S * 4 * W, GAVA_EPI_F32, pr, stream, w.X, W));
   }
   // ln_final on the EOT rows only, then text_projection (VitaCLIP_text_encoder.py:164-169)
-  TRY(ln(w.X, W, eot_index, m->lnf_g, m->lnf_b, w.EOT16, W, nullptr, 0, m->n_prompts, W, pr, stream));
-  TRY(gemm(w.EOT16, W, m->w_tproj, W, nullptr, out, m->E, m->n_prompts, m->E, W, GAVA_EPI_F32, pr, stream));
+  TRY(ln(w.X, W, eot_index, m->lnf_g, m->lnf_b, w.EOT16, S * W, nullptr, 0, m->n_prompts, W, pr, stream, sp));
+  TRY(gemm(w.EOT16, S * W, m->w_tproj, S * W, nullptr, out, m->E, m->n_prompts, m->E, S * W, GAVA_EPI_F32, pr, stream));
   return GAVA_OK;
 }

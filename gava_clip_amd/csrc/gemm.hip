@@ -30,6 +30,7 @@ struct GemmParams {
   int scale_cols; float scale;
   const float* pos; const float* time; int n_patches; int T;
   int tiles_n, n_tiles;
+  int split_out;
 };
 
 // issue the 4+4 global_load_lds_dwordx4 of this wave for one k-tile
@@ -45,7 +46,7 @@ static __device__ __forceinline__ void stage_tile(const unsigned short* const (&
   }
 }
 
-template <class P, int EPI, bool RES>
+template <class P, int EPI, bool RES, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x;
@@ -138,13 +139,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       const int n = nbase + j * 16;
       float v0 = acc[i][j][0] + bj[j].x, v1 = acc[i][j][1] + bj[j].y;
       float v2 = acc[i][j][2] + bj[j].z, v3 = acc[i][j][3] + bj[j].w;
-      if (EPI == GAVA_EPI_H16) {
-        if (n < p.scale_cols) { v0 *= p.scale; v1 *= p.scale; v2 *= p.scale; v3 *= p.scale; }
-        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + n) =
-            pack4<P>(v0, v1, v2, v3);
-      } else if (EPI == GAVA_EPI_H16_QGELU) {
-        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + n) =
-            pack4<P>(quick_gelu(v0), quick_gelu(v1), quick_gelu(v2), quick_gelu(v3));
+      if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU) {
+        if (EPI == GAVA_EPI_H16) {
+          if (n < p.scale_cols) { v0 *= p.scale; v1 *= p.scale; v2 *= p.scale; v3 *= p.scale; }
+        } else {
+          v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3);
+        }
+        unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + n;
+        if (SPLIT) {
+          uint2 hi, lo;
+          split4<P>(v0, v1, v2, v3, hi, lo);
+          *reinterpret_cast<uint2*>(o) = hi;
+          *reinterpret_cast<uint2*>(o + p.N) = lo;
+          *reinterpret_cast<uint2*>(o + 2 * p.N) = hi;
+        } else {
+          *reinterpret_cast<uint2*>(o) = pack4<P>(v0, v1, v2, v3);
+        }
       } else if (EPI == GAVA_EPI_F32) {
         if (RES) {
           const float4 rr = *reinterpret_cast<const float4*>(p.resid + orow * p.ldr + n);
@@ -166,13 +176,19 @@ template <class P>
 int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   dim3 grid(gp.n_tiles), block(256);
   switch (epi) {
-    case GAVA_EPI_H16: hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_H16, false>), grid, block, 0, s, gp); break;
-    case GAVA_EPI_H16_QGELU: hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_H16_QGELU, false>), grid, block, 0, s, gp); break;
-    case GAVA_EPI_F32:
-      if (gp.resid) hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_F32, true>), grid, block, 0, s, gp);
-      else hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_F32, false>), grid, block, 0, s, gp);
+    case GAVA_EPI_H16:
+      if (gp.split_out) hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_H16, false, true>), grid, block, 0, s, gp);
+      else hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_H16, false, false>), grid, block, 0, s, gp);
       break;
-    case GAVA_EPI_F32_PATCH: hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_F32_PATCH, false>), grid, block, 0, s, gp); break;
+    case GAVA_EPI_H16_QGELU:
+      if (gp.split_out) hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_H16_QGELU, false, true>), grid, block, 0, s, gp);
+      else hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_H16_QGELU, false, false>), grid, block, 0, s, gp);
+      break;
+    case GAVA_EPI_F32:
+      if (gp.resid) hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_F32, true, false>), grid, block, 0, s, gp);
+      else hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_F32, false, false>), grid, block, 0, s, gp);
+      break;
+    case GAVA_EPI_F32_PATCH: hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_F32_PATCH, false, false>), grid, block, 0, s, gp); break;
     default: return GAVA_EINVAL;
   }
   GAVA_CHECK_LAUNCH();
@@ -188,7 +204,8 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   if (a->lda % 8 || a->ldw % 8 || a->lda < a->K || a->ldw < a->K) return GAVA_EINVAL;
   if (((uintptr_t)a->A | (uintptr_t)a->W | (uintptr_t)a->out) & 15) return GAVA_EINVAL;
   if (a->bias && ((uintptr_t)a->bias & 15)) return GAVA_EINVAL;
-  if (a->ldo % 4 || a->ldo < a->N) return GAVA_EINVAL;
+  if (a->ldo % 4 || a->ldo < (a->split_out ? 3 : 1) * (int64_t)a->N) return GAVA_EINVAL;
+  if (a->split_out && a->epilogue != GAVA_EPI_H16 && a->epilogue != GAVA_EPI_H16_QGELU) return GAVA_EINVAL;
   if (a->epilogue == GAVA_EPI_F32 && a->resid && (a->ldr % 4 || ((uintptr_t)a->resid & 15))) return GAVA_EINVAL;
   if (a->epilogue == GAVA_EPI_F32_PATCH &&
       (!a->pos || !a->time || a->n_patches <= 0 || a->T <= 0 || a->M % a->n_patches)) return GAVA_EINVAL;
@@ -200,6 +217,7 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.M = a->M; gp.N = a->N; gp.K = a->K;
   gp.scale_cols = a->scale_cols; gp.scale = a->scale;
   gp.pos = a->pos; gp.time = a->time; gp.n_patches = a->n_patches; gp.T = a->T;
+  gp.split_out = a->split_out;
   gp.tiles_n = a->N / BN;
   gp.n_tiles = gp.tiles_n * ((a->M + BM - 1) / BM);
   hipStream_t s = (hipStream_t)stream;

@@ -40,7 +40,7 @@ struct LnParams {
   const float* gamma; const float* beta;
   unsigned short* out16; long o16_stride;
   float* out32; long o32_stride;
-  int rows, D;
+  int rows, D, split;
 };
 
 template <class P>
@@ -74,7 +74,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
   for (int i = 0; i < MAXV; ++i)
     if (act[i]) {
       const int c = (lane + 64 * i) * 4;
-      if (p.out16) store_h16x4<P>(p.out16 + (long)row * p.o16_stride + c, v[i]);
+      if (p.out16) {
+        unsigned short* o = p.out16 + (long)row * p.o16_stride + c;
+        if (p.split) {
+          uint2 hi, lo;
+          split4<P>(v[i].x, v[i].y, v[i].z, v[i].w, hi, lo);
+          *reinterpret_cast<uint2*>(o) = hi;
+          *reinterpret_cast<uint2*>(o + p.D) = lo;
+          *reinterpret_cast<uint2*>(o + 2 * p.D) = hi;
+        } else {
+          store_h16x4<P>(o, v[i]);
+        }
+      }
       if (p.out32) *reinterpret_cast<float4*>(p.out32 + (long)row * p.o32_stride + c) = v[i];
     }
 }
@@ -269,10 +280,11 @@ extern "C" int gava_layernorm(const gava_layernorm_args* a, gava_stream_t stream
   if (!a || !a->in || a->rows <= 0) return GAVA_EINVAL;
   if (a->D % 4 || a->D > 256 * MAXV || a->D <= 0) return GAVA_EINVAL;
   if (!a->out16 && !a->out32) return GAVA_EINVAL;
+  if (a->split_out && (!a->out16 || a->out16_stride < 3 * (int64_t)a->D)) return GAVA_EINVAL;
   if (a->gamma && !a->beta) return GAVA_EINVAL;
   if (a->in_stride % 4 || (a->out16 && a->out16_stride % 4) || (a->out32 && a->out32_stride % 4)) return GAVA_EINVAL;
   LnParams p{a->in, a->in_stride, a->in_row_index, a->gamma, a->beta, (unsigned short*)a->out16,
-             a->out16_stride, a->out32, a->out32_stride, a->rows, a->D};
+             a->out16_stride, a->out32, a->out32_stride, a->rows, a->D, a->split_out};
   dim3 grid((a->rows + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (a->prec == GAVA_PREC_F16) hipLaunchKernelGGL(layernorm_kernel<PrecF16>, grid, block, 0, s, p);

@@ -28,13 +28,13 @@ class GemmArgs(C.Structure):
                 ("out", _vp), ("ldo", C.c_int64), ("resid", _fp), ("ldr", C.c_int64),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int), ("prec", C.c_int),
                 ("scale_cols", C.c_int), ("scale", C.c_float),
-                ("pos", _fp), ("time", _fp), ("n_patches", C.c_int), ("T", C.c_int)]
+                ("pos", _fp), ("time", _fp), ("n_patches", C.c_int), ("T", C.c_int), ("split_out", C.c_int)]
 
 
 class LayerNormArgs(C.Structure):
     _fields_ = [("inp", _fp), ("in_stride", C.c_int64), ("in_row_index", _ip), ("gamma", _fp), ("beta", _fp),
                 ("out16", _vp), ("out16_stride", C.c_int64), ("out32", _fp), ("out32_stride", C.c_int64),
-                ("rows", C.c_int), ("D", C.c_int), ("prec", C.c_int)]
+                ("rows", C.c_int), ("D", C.c_int), ("prec", C.c_int), ("split_out", C.c_int)]
 
 
 class AttentionArgs(C.Structure):
@@ -43,7 +43,7 @@ class AttentionArgs(C.Structure):
                 ("out", _vp), ("ld_out", C.c_int64),
                 ("batch", C.c_int), ("heads", C.c_int), ("n_q", C.c_int), ("n_kmain", C.c_int),
                 ("n_g", C.c_int), ("T", C.c_int), ("has_summary", C.c_int),
-                ("causal", C.c_int), ("prec", C.c_int)]
+                ("causal", C.c_int), ("prec", C.c_int), ("split_out", C.c_int)]
 
 
 class VisionLayer(C.Structure):
@@ -70,7 +70,7 @@ class TextLayer(C.Structure):
 
 class TextModel(C.Structure):
     _fields_ = [("n_prompts", C.c_int), ("L", C.c_int), ("W", C.c_int), ("H", C.c_int), ("layers", C.c_int),
-                ("E", C.c_int), ("n_ctx", C.c_int), ("prec", C.c_int),
+                ("E", C.c_int), ("n_ctx", C.c_int), ("prec", C.c_int), ("split", C.c_int),
                 ("token_embedding", _fp), ("positional_embedding", _fp), ("lnf_g", _fp), ("lnf_b", _fp),
                 ("w_tproj", _vp), ("layer", C.POINTER(TextLayer))]
 
@@ -141,7 +141,7 @@ def h16_dtype(prec):
 # ---- thin per-op wrappers (used by the unit tests; the model uses the fused drivers) ----------
 
 def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0,
-         pos=None, time=None, n_patches=0, T=0, M=None):
+         pos=None, time=None, n_patches=0, T=0, M=None, split_out=False):
     a = GemmArgs()
     a.A, a.lda, a.W, a.ldw = ptr(A), A.stride(0), ptr(W), W.stride(0)
     a.bias, a.out, a.ldo = ptr(bias), ptr(out), out.stride(0)
@@ -149,21 +149,24 @@ def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0
     a.M, a.N, a.K = (A.shape[0] if M is None else M), W.shape[0], W.shape[1]
     a.epilogue, a.prec, a.scale_cols, a.scale = epilogue, prec, scale_cols, scale
     a.pos, a.time, a.n_patches, a.T = ptr(pos), ptr(time), n_patches, T
+    a.split_out = int(split_out)
     check(load().gava_gemm(C.byref(a), stream_ptr()), "gava_gemm")
 
 
-def layernorm(x, gamma, beta, *, out16=None, out32=None, prec, rows=None, in_stride=None, row_index=None):
+def layernorm(x, gamma, beta, *, out16=None, out32=None, prec, rows=None, in_stride=None, row_index=None,
+              split_out=False):
     a = LayerNormArgs()
     a.inp, a.in_stride, a.in_row_index = ptr(x), (x.stride(0) if in_stride is None else in_stride), ptr(row_index)
     a.gamma, a.beta = ptr(gamma), ptr(beta)
     a.out16, a.out16_stride = ptr(out16), (out16.stride(0) if out16 is not None else 0)
     a.out32, a.out32_stride = ptr(out32), (out32.stride(0) if out32 is not None else 0)
     a.rows, a.D, a.prec = (x.shape[0] if rows is None else rows), x.shape[-1], prec
+    a.split_out = int(split_out)
     check(load().gava_layernorm(C.byref(a), stream_ptr()), "gava_layernorm")
 
 
 def attention(q, k, v, out, *, batch, heads, n_q, n_kmain, prec, causal=False,
-              side_k=None, side_v=None, n_g=0, T=0, has_summary=False):
+              side_k=None, side_v=None, n_g=0, T=0, has_summary=False, split_out=False):
     a = AttentionArgs()
     a.q, a.k, a.v, a.ld_qkv = ptr(q), ptr(k), ptr(v), q.stride(0)
     a.side_k, a.side_v = ptr(side_k), ptr(side_v)
@@ -171,7 +174,16 @@ def attention(q, k, v, out, *, batch, heads, n_q, n_kmain, prec, causal=False,
     a.out, a.ld_out = ptr(out), out.stride(0)
     a.batch, a.heads, a.n_q, a.n_kmain = batch, heads, n_q, n_kmain
     a.n_g, a.T, a.has_summary, a.causal, a.prec = n_g, T, int(has_summary), int(causal), prec
+    a.split_out = int(split_out)
     check(load().gava_attention(C.byref(a), stream_ptr()), "gava_attention")
+
+
+def split_pack_weight(w, prec):
+    """[N][K] fp32 -> [N][3K] h16 = [W_hi | W_hi | W_lo], the weight side of the split-precision GEMM."""
+    w = w.detach().float().contiguous()
+    hi = convert_h16(w, prec)
+    lo = convert_h16(w - hi.float(), prec)
+    return torch.cat([hi, hi, lo], dim=1).contiguous()
 
 
 def convert_h16(x, prec):

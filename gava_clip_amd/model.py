@@ -306,6 +306,9 @@ class VitaCLIP(nn.Module):
         # ---- HIP-path state (not part of the reference surface)
         operand_dtype = operand_dtype or os.environ.get("GAVA_PREC", "fp16")
         self.prec = hip.PREC_NAMES[operand_dtype]
+        # text tower GEMMs in split precision (hi+lo operands, 3 MFMA passes): the text side is <1 % of
+        # the work at the headline configs but dominates the logits error at plain 16-bit operands
+        self.text_split_precision = os.environ.get("GAVA_TEXT_SPLIT", "1") != "0"
         self.gather_across_ranks = True     # RCCL all-gather of clip embeddings when world_size > 1
         self.debug_taps = False             # keep per-layer CLS rows of the last forward
         self._shape = dict(size=input_size[0], P=patch_size[0], D=feature_dim, H=num_heads, layers=num_layers,
@@ -324,7 +327,7 @@ class VitaCLIP(nn.Module):
 
     def _pack_key(self):
         ps = list(self.parameters())
-        return (self.prec, ps[0].device, ps[0].data_ptr(), sum(p._version for p in ps))
+        return (self.prec, self.text_split_precision, ps[0].device, ps[0].data_ptr(), sum(p._version for p in ps))
 
     def _h16(self, t):
         return hip.convert_h16(t.detach().float(), self.prec)
@@ -351,7 +354,7 @@ class VitaCLIP(nn.Module):
                    cls_token=K(self._f32(v.cls_token)), pos_embed=K(self._f32(v.pos_embed)),
                    lnpre_g=K(self._f32(v.ln_pre.weight)), lnpre_b=K(self._f32(v.ln_pre.bias)),
                    lnpost_g=K(self._f32(v.ln_post.weight)), lnpost_b=K(self._f32(v.ln_post.bias)),
-                   w_proj=K(self._h16(v.proj.detach().float().t().contiguous())))
+                   w_proj=K(hip.split_pack_weight(v.proj.detach().float().t(), self.prec)))
         layers = (hip.VisionLayer * sh["layers"])()
         for i, blk in enumerate(v.blocks):
             a, s = blk.attn, blk.summary_attn_layer
@@ -374,12 +377,13 @@ class VitaCLIP(nn.Module):
         if self.use_text_prompt_learning:
             t = self.textual
             tlayers = (hip.TextLayer * sh["TL"])()
+            tw = (lambda w: hip.split_pack_weight(w, self.prec)) if self.text_split_precision else self._h16
             for i, blk in enumerate(t.transformer.resblocks):
                 L = tlayers[i]
-                L.w_qkv, L.b_qkv = K(self._h16(blk.attn.in_proj_weight)), K(self._f32(blk.attn.in_proj_bias))
-                L.w_out, L.b_out = K(self._h16(blk.attn.out_proj.weight)), K(self._f32(blk.attn.out_proj.bias))
-                L.w_fc, L.b_fc = K(self._h16(blk.mlp.c_fc.weight)), K(self._f32(blk.mlp.c_fc.bias))
-                L.w_proj, L.b_proj = K(self._h16(blk.mlp.c_proj.weight)), K(self._f32(blk.mlp.c_proj.bias))
+                L.w_qkv, L.b_qkv = K(tw(blk.attn.in_proj_weight)), K(self._f32(blk.attn.in_proj_bias))
+                L.w_out, L.b_out = K(tw(blk.attn.out_proj.weight)), K(self._f32(blk.attn.out_proj.bias))
+                L.w_fc, L.b_fc = K(tw(blk.mlp.c_fc.weight)), K(self._f32(blk.mlp.c_fc.bias))
+                L.w_proj, L.b_proj = K(tw(blk.mlp.c_proj.weight)), K(self._f32(blk.mlp.c_proj.bias))
                 L.ln1_g, L.ln1_b = K(self._f32(blk.ln_1.weight)), K(self._f32(blk.ln_1.bias))
                 L.ln2_g, L.ln2_b = K(self._f32(blk.ln_2.weight)), K(self._f32(blk.ln_2.bias))
             dev = t.token_embedding.weight.device
@@ -390,7 +394,7 @@ class VitaCLIP(nn.Module):
             packed.update(txt=dict(token_embedding=K(self._f32(t.token_embedding.weight)),
                                    positional_embedding=K(self._f32(t.positional_embedding)),
                                    lnf_g=K(self._f32(t.ln_final.weight)), lnf_b=K(self._f32(t.ln_final.bias)),
-                                   w_tproj=K(self._h16(t.text_projection.detach().float().t().contiguous()))),
+                                   w_tproj=K(tw(t.text_projection.detach().float().t().contiguous()))),
                           txt_layers=tlayers, tokens=tok, eot=eot)
         self._packed, self._packed_key = packed, key
         return packed
@@ -447,6 +451,7 @@ class VitaCLIP(nn.Module):
         m = hip.TextModel()
         m.n_prompts, m.L, m.W, m.H, m.layers = n, sh["L"], sh["W"], sh["TH"], sh["TL"]
         m.E, m.n_ctx, m.prec = sh["E"], sh["n_ctx"], self.prec
+        m.split = int(self.text_split_precision)
         for k, val in pk["txt"].items():
             setattr(m, k, val)
         m.layer = C.cast(pk["txt_layers"], C.POINTER(hip.TextLayer))

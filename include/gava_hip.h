@@ -62,6 +62,10 @@ typedef struct {
    * frame*(n_patches+1) + 1 + p with + pos[(1+p)][:] + time[(frame % T)][:]
    * (VitaCLIP_vision_encoder.py:108-111,86-100). */
   const float* pos; const float* time; int n_patches; int T;
+  /* EPI_H16 / EPI_H16_QGELU: split-precision output.  Row layout becomes [hi(N) | lo(N) | hi(N)]
+   * (ldo >= 3N) with lo = h16(v - hi): the A operand of a following GEMM whose weight is packed
+   * [W_hi | W_hi | W_lo] (K' = 3K), i.e. A_hi W_hi + A_lo W_hi + A_hi W_lo in one pass. */
+  int split_out;
 } gava_gemm_args;
 int gava_gemm(const gava_gemm_args* a, gava_stream_t stream);
 
@@ -75,6 +79,7 @@ typedef struct {
   void* out16; int64_t out16_stride;     /* may be NULL */
   float* out32; int64_t out32_stride;    /* may be NULL; may alias in */
   int rows, D, prec;
+  int split_out;                         /* out16 row = [hi(D) | lo(D) | hi(D)], see gava_gemm_args */
 } gava_layernorm_args;
 int gava_layernorm(const gava_layernorm_args* a, gava_stream_t stream);
 
@@ -96,6 +101,7 @@ typedef struct {
   int batch, heads, n_q, n_kmain;
   int n_g, T, has_summary;                                       /* side-row structure      */
   int causal, prec;
+  int split_out;   /* out row = [hi(heads*64) | lo | hi], see gava_gemm_args */
 } gava_attention_args;
 int gava_attention(const gava_attention_args* a, gava_stream_t stream);
 
@@ -122,7 +128,8 @@ typedef struct {
   const void* w_patch; const float* b_patch;   /* [D][Kp] h16, Kp = 3*P*P rounded up to 64   */
   const float* cls_token; const float* pos_embed; const float* time_embed; /* time: [T_in][D] */
   const float* lnpre_g; const float* lnpre_b; const float* lnpost_g; const float* lnpost_b;
-  const void* w_proj;                          /* visual.proj transposed: [E][D] h16          */
+  const void* w_proj;                          /* visual.proj transposed, split-packed: [E][3D] =
+                                                  [W_hi | W_hi | W_lo] h16 (see gava_gemm_args)  */
   const gava_vision_layer* layer;              /* host array [layers]                         */
 } gava_vision_model;
 
@@ -145,6 +152,8 @@ typedef struct {                 /* ResidualAttentionBlock, VitaCLIP_text_encode
 
 typedef struct {
   int n_prompts, L, W, H, layers, E, n_ctx, prec;
+  int split;                               /* 1: split-precision GEMMs; every weight below is then
+                                              packed [W_hi | W_hi | W_lo] with 3x the columns    */
   const float* token_embedding;            /* [vocab][W] fp32                                */
   const float* positional_embedding;       /* [L][W]                                         */
   const float* lnf_g; const float* lnf_b;

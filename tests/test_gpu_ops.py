@@ -182,3 +182,27 @@ def test_similarity_head():
     assert torch.allclose(vn, vr, rtol=1e-6, atol=1e-7)
     assert torch.allclose(tf, tr / tr.norm(dim=-1, keepdim=True), rtol=1e-6, atol=1e-7)
     assert torch.allclose(logits, ls.exp() * vr @ tr.t(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("prec,tol", [(hip.PREC_F16, 2e-5), (hip.PREC_BF16, 2e-4)])
+def test_split_precision_chain(prec, tol):
+    """LN(split) -> GEMM(QGELU, split out) -> GEMM with [W_hi|W_hi|W_lo] weights tracks the fp32 chain
+    ~100x closer than plain 16-bit operands (3 MFMA passes per product)."""
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    M, D, F = 200, 256, 512
+    x = rnd((M, D), 2.0, 41).to(d)
+    g, b = (1 + rnd((D,), 0.1, 42)).to(d), rnd((D,), 0.1, 43).to(d)
+    W1, b1 = rnd((F, D), D ** -0.5, 44).to(d), rnd((F,), 0.1, 45).to(d)
+    W2, b2 = rnd((D, F), F ** -0.5, 46).to(d), rnd((D,), 0.1, 47).to(d)
+    xn = torch.zeros(M, 3 * D, dtype=dt, device=d)
+    hip.layernorm(x, g, b, out16=xn, prec=prec, split_out=True)
+    h = torch.zeros(M, 3 * F, dtype=dt, device=d)
+    hip.gemm(xn, hip.split_pack_weight(W1, prec), b1, h, epilogue=hip.EPI_H16_QGELU, prec=prec, split_out=True)
+    out = torch.zeros(M, D, device=d)
+    hip.gemm(h, hip.split_pack_weight(W2, prec), b2, out, epilogue=hip.EPI_F32, prec=prec)
+    r = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-5).double() @ W1.double().t() + b1
+    r = r * torch.sigmoid(1.702 * r)
+    ref = (r @ W2.double().t() + b2).float()
+    err = float((out - ref).abs().max() / ref.abs().max())
+    assert err < tol, err
