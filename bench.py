@@ -1,0 +1,265 @@
+#!/usr/bin/env python
+"""bench.py — clips/sec of the GaVA-CLIP video-frame forward path on N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one VitaCLIP.forward() (vision tower + text tower + RCCL all-gather of the clip
+embeddings + similarity head) over one synthetic batch of 64 clips per GPU (BASELINE.json
+configs[1] / configs[3]; weak scaling).  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line (contract in the task statement), extended with
+  roofline      — the dominant kernel (the vision fc1 MFMA GEMM) timed stand-alone with HIP events
+  cpu_baseline  — the oracle (CPU port of the reference) timed on the host cores, N=1 only
+  kernels       — stand-alone HIP-event timings of every hot kernel shape of one layer
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import torch  # noqa: E402
+
+T_START = time.perf_counter()
+
+
+def log(msg):
+    """progress to stderr (the JSON line on stdout stays alone)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("GAVA_CPU_THREADS", "16"))))   # a 1-GPU box's CPU share is 16
+
+
+PEAK_MFMA_TFLOPS = 2500.0   # dense bf16/fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+CONFIGS = {
+    # name: (VitaConfig name, clips per GPU, class file, description)
+    "c2": ("VIT_B16_T8", 64, "updrs_3cls_classes.txt", "ViT-B/16, 8 frames, 224^2, batch 64/GPU, 3 classes"),
+    "c3": ("VIT_B16_T16", 32, "k400_classes.txt", "ViT-B/16, 16 frames, 224^2, batch 32/GPU, 400 classes"),
+    "c1": ("VIT_B16_T8", 2, "updrs_3cls_classes.txt", "ViT-B/16, 8 frames, 224^2, batch 2, 3 classes"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--prec", default=os.environ.get("GAVA_PREC", "fp16"), choices=["fp16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the stand-alone kernel timings")
+    ap.add_argument("--no-alt", action="store_true", help="skip the short run in the other operand dtype")
+    return ap.parse_args()
+
+
+def timed_steps(fn, steps, warmup, dist=None):
+    """W untimed + exactly K timed calls, bracketed by barrier + synchronize; seconds (max over ranks)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def event_time_ms(fn, iters=10, warmup=3):
+    """Average duration of fn's launches, HIP events on the stream the kernels run on (torch's current)."""
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_table(cfg, B, prec):
+    """Stand-alone timings of the per-layer kernels at this config's shapes (through the C ABI)."""
+    from gava_clip_amd import hip
+    dt = hip.h16_dtype(prec)
+    d = torch.device("cuda")
+    D, F, H = cfg.feature_dim, cfg.mlp_dim, cfg.num_heads
+    T, G, n1 = cfg.num_frames, cfg.num_global_prompts, cfg.tokens_main
+    BT = B * T
+    R = BT * n1
+    g = torch.Generator(device="cuda").manual_seed(1)
+
+    def rn(*s, scale=1.0, dtype=dt):
+        return (torch.randn(*s, device=d, generator=g) * scale).to(dtype)
+
+    Xn, MIX, HID = rn(R, D), rn(R, D), rn(R, F)
+    X = rn(R, D, dtype=torch.float32)
+    QKV = rn(R, 3 * D)
+    Wqkv, Wo, W1, W2 = rn(3 * D, D, scale=D ** -0.5), rn(D, D, scale=D ** -0.5), rn(F, D, scale=D ** -0.5), rn(D, F, scale=F ** -0.5)
+    bq, bo, b1, b2 = (rn(n, dtype=torch.float32) for n in (3 * D, D, F, D))
+    gam, bet = rn(D, dtype=torch.float32), rn(D, dtype=torch.float32)
+    side = rn(G + 2 * BT, 2 * D)
+    rows = []
+
+    def add(name, fn, flops, bytes_):
+        ms = event_time_ms(fn)
+        rows.append(dict(kernel=name, ms=round(ms, 4), tflops=round(flops / ms / 1e9, 1) if flops else None,
+                         gbps=round(bytes_ / ms / 1e6, 1), flops=flops, bytes=bytes_))
+
+    add("layernorm f32->h16 [R,D]", lambda: hip.layernorm(X, gam, bet, out16=Xn, prec=prec), 0, R * D * 6)
+    add("gemm qkv  [R,D]x[3D,D] h16", lambda: hip.gemm(Xn, Wqkv, bq, QKV, epilogue=hip.EPI_H16, prec=prec, scale_cols=D, scale=0.125),
+        2.0 * R * 3 * D * D, R * D * 2 + R * 3 * D * 2 + 3 * D * D * 2)
+    add("attention (frame,head) 197q x %dk" % cfg.attn_keys(),
+        lambda: hip.attention(QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:], MIX, batch=BT, heads=H, n_q=n1, n_kmain=n1, prec=prec,
+                              side_k=side[:, :D], side_v=side[:, D:], n_g=G, T=T, has_summary=True),
+        4.0 * BT * H * n1 * cfg.attn_keys() * 64, R * 3 * D * 2 + R * D * 2)
+    add("gemm out  [R,D]x[D,D] +res f32", lambda: hip.gemm(MIX, Wo, bo, X, epilogue=hip.EPI_F32, prec=prec, resid=X),
+        2.0 * R * D * D, R * D * 2 + R * D * 8 + D * D * 2)
+    add("gemm fc1  [R,D]x[F,D] qgelu h16", lambda: hip.gemm(Xn, W1, b1, HID, epilogue=hip.EPI_H16_QGELU, prec=prec),
+        2.0 * R * F * D, R * D * 2 + R * F * 2 + F * D * 2)
+    add("gemm fc2  [R,F]x[D,F] +res f32", lambda: hip.gemm(HID, W2, b2, X, epilogue=hip.EPI_F32, prec=prec, resid=X),
+        2.0 * R * D * F, R * F * 2 + R * D * 8 + D * F * 2)
+    return rows
+
+
+def cpu_baseline():
+    """The oracle (CPU port of the reference forward) at BASELINE config c1: B=2, T=8, 3 classes, fp32."""
+    import numpy as np
+    from gava_clip_amd import synth
+    from gava_clip_amd.config import VIT_B16_T8
+    from gava_clip_amd.tokenizer import tokenize, read_class_names, prompt_texts
+    from oracle.vita_oracle import Oracle   # timed as the CPU baseline, never on the product path
+    from helpers import CLASSES_3, synth_torch_state
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle at c1 on {cores} threads")
+    cfg = VIT_B16_T8
+    sd = synth_torch_state(cfg, 3)
+    tok = tokenize(prompt_texts(read_class_names(CLASSES_3), cfg.text_num_prompts))
+    o = Oracle(cfg, sd, tok)
+    x = torch.from_numpy(synth.synth_clip(2, 8, 224))
+    t0 = time.perf_counter()
+    o.forward(x)
+    log(f"cpu_baseline: warm-up forward {time.perf_counter() - t0:.2f}s")
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        o.forward(x)
+        ts.append(time.perf_counter() - t0)
+        log(f"cpu_baseline: forward {ts[-1]:.2f}s")
+    best = min(ts)
+    return dict(value=round(2 / best, 3), unit="clips/s", cores=torch.get_num_threads(), kind="port",
+                sample="oracle/vita_oracle.py fp32, config c1 (B=2,T=8,224^2,3 classes), best of 3 forwards, "
+                       f"{best:.3f} s/forward, torch {torch.__version__} CPU")
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
+
+    import gava_clip_amd.config as C
+    from gava_clip_amd import VitaCLIP, flops as fl
+    from helpers import model_kwargs
+    cname, B, cls_file, desc = CONFIGS[a.config]
+    cfg = getattr(C, cname)
+    cls_path = os.path.join(REPO, "gava_clip_amd", "data", "classes", cls_file)
+    torch.set_num_threads(host_cores())
+    log(f"building {cname} model, {B} clips/GPU, {world} GPU(s), operands {a.prec}")
+    torch.manual_seed(0)                      # identical random-init weights on every rank
+    model = VitaCLIP(**model_kwargs(cfg, cls_path), operand_dtype=a.prec).cuda().eval()
+    n_cls = len(model.tokenized_prompts)
+    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    x = torch.randn(B, 3, cfg.num_frames, cfg.input_size, cfg.input_size, device="cuda", generator=gen)
+
+    def step():
+        with torch.no_grad():
+            return model(x)
+
+    log("model on device; first forward (packs weights)")
+    step(); torch.cuda.synchronize()
+    log("timed region")
+    secs = timed_steps(step, a.steps, a.warmup, dist)
+    log(f"{a.steps} steps in {secs:.3f}s")
+    logits = step()[0]
+    assert tuple(logits.shape) == (B * world, n_cls) and bool(torch.isfinite(logits).all())
+    clips = world * B * a.steps
+    value = clips / secs
+    fwd_flops = fl.forward_flops(cfg, B, n_cls)
+
+    out = {
+        "metric": "clips/sec (8-frame 224^2 ViT-B/16 VitaCLIP.forward)", "value": round(value, 2), "unit": "clips/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * secs / a.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.prec, "data": "synthetic",
+        "config": {"workload": f"{a.config}: {desc}", "clips_per_gpu": B, "global_batch": B * world,
+                   "frames": cfg.num_frames, "classes": n_cls, "weights": "random-init",
+                   "parallelism": f"clips sharded over {world} GPU(s); RCCL all-gather of (B,E) embeddings" if world > 1 else "single GPU",
+                   "text_tower": "split-precision (3 MFMA passes)" if model.text_split_precision else a.prec},
+        "algorithmic_tflops": round(fwd_flops * world * a.steps / secs / 1e12, 1),
+        "mfma_frac_whole_forward": round(fwd_flops * a.steps / secs / 1e12 / PEAK_MFMA_TFLOPS, 4),
+    }
+    if rank == 0 and not a.no_kernels:
+        log("stand-alone kernel timings")
+        rows = kernel_table(cfg, B, model.prec)
+        out["kernels"] = [{k: r[k] for k in ("kernel", "ms", "tflops", "gbps")} for r in rows]
+        fc1 = next(r for r in rows if r["kernel"].startswith("gemm fc1"))
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")   # HBM bytes/launch from the committed PMC passes
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("gemm_fc1_bytes_per_launch")
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<.., EPI_H16_QGELU> (vision fc1, M=%d N=%d K=%d)" % (
+                               B * cfg.num_frames * cfg.tokens_main, cfg.mlp_dim, cfg.feature_dim),
+                           "achieved": fc1["tflops"], "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(fc1["tflops"] / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
+                           "flops_per_launch": fc1["flops"], "ms_per_launch": fc1["ms"]}
+    if rank == 0 and not a.no_alt:
+        log("alt operand dtype run")
+        other = "bf16" if a.prec == "fp16" else "fp16"
+        model.set_operand_dtype(other)
+        s2 = timed_steps(step, max(3, a.steps // 4), 2, None) if world == 1 else None
+        model.set_operand_dtype(a.prec)
+        if s2 is not None:
+            out["alt"] = {"dtype": other, "value": round(B * max(3, a.steps // 4) / s2, 2), "unit": "clips/s"}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -66,7 +66,7 @@ static __device__ __forceinline__ float wave_sum(float v) {
 
 static __device__ __forceinline__ float quick_gelu(float x) {
   // x * sigmoid(1.702 x)  (VitaCLIP_vision_encoder_utils.py:18-20)
-  return x / (1.0f + __expf(-1.702f * x));
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
 }
 
 #define GAVA_CHECK_LAUNCH()                                   \

@@ -1,24 +1,26 @@
 // gemm.hip — C[M,N] = A[M,K]·W[N,K]^T, 16-bit operands (fp16|bf16), fp32 accumulate, fused epilogue.
 //
-// gfx950 design (v1, "2-phase"):
-//   * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
-//     4x4 MFMA 16x16x32 accumulators), BK = 64, two LDS stages of (16 KiB A + 16 KiB W) = 64 KiB
-//     -> two workgroups per CU, one k-tile of prefetch in flight behind the MFMAs.
-//   * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging).  The LDS image
-//     is lane-linear per wave instruction, so the bank-conflict swizzle (16-byte chunk index
-//     XOR ((row>>1)&7)) is applied to the per-lane SOURCE address and again on the ds_read_b128.
+// gfx950 design (v2):
+//   * BM x BN output tile per workgroup, one wave per 64x64 sub-tile (4x4 MFMA 16x16x32
+//     accumulators, 64 VGPRs).  Default 256x128 -> 8 waves, two per SIMD, one workgroup per CU.
+//   * operands go L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging) into an NST-deep ring
+//     of BK = 64 stages (3 x 48 KiB).  Loads run NST-1 k-tiles ahead of the MFMAs behind a
+//     COUNTED s_waitcnt vmcnt(N) and a raw s_barrier (one barrier per k-tile; __syncthreads()
+//     would drain the ring with vmcnt(0)).
+//   * the LDS image of a glds is lane-linear, so the bank-conflict swizzle (16-byte chunk index
+//     XOR ((row>>1)&7), measured SQ_LDS_BANK_CONFLICT = 0) sits on the per-lane SOURCE address and
+//     again on the ds_read_b128.
 //   * MFMA operands are swapped (A-operand = weight rows, B-operand = activation rows) so each
 //     lane ends with 4 consecutive output COLUMNS of one row: 16-byte fp32 / 8-byte h16 stores
 //     and one float4 bias load per accumulator.
-//   * workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of
-//     tiles, n-tile fastest: the A row-panel is fetched from HBM once per XCD and W stays in L2.
+//   * workgroup -> tile map: each XCD (private 4 MiB L2) walks a contiguous range of tiles, and
+//     inside it tiles are ordered in SM x SN super-tiles whose operand panels fit that L2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
+constexpr int BK = 64;
 
 struct GemmParams {
   const unsigned short* A; long lda;
@@ -29,58 +31,74 @@ struct GemmParams {
   int M, N, K;
   int scale_cols; float scale;
   const float* pos; const float* time; int n_patches; int T;
-  int tiles_n, n_tiles;
+  int tiles_m, tiles_n, n_tiles;
   int split_out;
+  int sm, sn;   // super-tile shape (in tiles)
+  int ablate;   // debug only (GAVA_GEMM_ABLATE): 1 = no staging loads after the prologue, 2 = no LDS reads/MFMA
 };
 
-// issue the 4+4 global_load_lds_dwordx4 of this wave for one k-tile
-static __device__ __forceinline__ void stage_tile(const unsigned short* const (&srcA)[4],
-                                                  const unsigned short* const (&srcW)[4],
-                                                  long koff, char* lds_stage, int wave) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    char* dstA = lds_stage + (wave * 4 + i) * 1024;
-    char* dstW = dstA + TILE_BYTES;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(srcA[i] + koff), LDS_PTR(void, dstA), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(GLB_PTR(srcW[i] + koff), LDS_PTR(void, dstW), 16, 0, 0);
-  }
-}
-
-template <class P, int EPI, bool RES, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+template <class P, int EPI, bool RES, bool SPLIT, int BM, int BN, int NST>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2)
+void gemm_kernel(const GemmParams p) {
+  constexpr int NW = (BM / 64) * (BN / 64);       // waves
+  constexpr int WN = BN / 64;                     // waves along n
+  constexpr int A_BYTES = BM * BK * 2;
+  constexpr int STAGE = (BM + BN) * BK * 2;
+  constexpr int PIECES = (BM + BN) / 8;           // 1 KiB glds pieces (8 rows x 128 B) per stage
+  constexpr int PPW = PIECES / NW;                // pieces per wave
+  static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+  static_assert(NST >= 2 && NST <= 4, "ring depth");
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
 
-  // XCD-aware, bijective block -> tile map (8 XCDs, blocks dealt round-robin)
-  const int nwg = p.n_tiles;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int nt = wg % p.tiles_n, mt = wg / p.tiles_n;
+  // ---- block -> tile: XCD-contiguous (bijective for any grid), then SM x SN super-tiles
+  int mt, nt;
+  {
+    const int nwg = p.n_tiles, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int per_group = p.sm * p.tiles_n;
+    const int g = wg / per_group;
+    const int first_m = g * p.sm;
+    const int sm = min(p.sm, p.tiles_m - first_m);
+    const int w = wg - g * per_group;
+    const int chunk = w / (sm * p.sn), rr = w - chunk * (sm * p.sn);
+    mt = first_m + rr % sm;
+    nt = chunk * p.sn + rr / sm;
+  }
   const int m0 = mt * BM, n0 = nt * BN;
 
-  // per-lane source pointers for the staging loads (swizzle on the source side)
-  const unsigned short* srcA[4];
-  const unsigned short* srcW[4];
+  // ---- per-lane source pointers of this wave's staging pieces (swizzle on the source side)
+  const unsigned short* src[PPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+  for (int i = 0; i < PPW; ++i) {
+    const int piece = wave + i * NW;
+    const int row = piece * 8 + (lane >> 3);          // row in the stacked [A;W] tile
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    int gm = m0 + row;
-    gm = gm < p.M ? gm : p.M - 1;
-    srcA[i] = p.A + (long)gm * p.lda + chunk * 8;
-    srcW[i] = p.W + (long)(n0 + row) * p.ldw + chunk * 8;
+    if (piece < BM / 8) {
+      int gm = m0 + row;
+      gm = gm < p.M ? gm : p.M - 1;
+      src[i] = p.A + (long)gm * p.lda + chunk * 8;
+    } else {
+      src[i] = p.W + (long)(n0 + row - BM) * p.ldw + chunk * 8;
+    }
   }
+  auto stage = [&](int kt) {
+    char* base = smem + (kt % NST) * STAGE;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + (long)kt * BK), LDS_PTR(void, base + (wave + i * NW) * 1024), 16, 0, 0);
+  };
 
-  // per-lane fragment read offsets (bytes) inside a tile
+  // per-lane fragment read offsets (bytes) inside a stage
   const int fr = lane & 15, fg = lane >> 4;
   const int swz = fr >> 1;
   const int offk0 = ((fg ^ swz) << 4), offk1 = (((4 + fg) ^ swz) << 4);
   const int a_row_off = (wr * 64 + fr) * 128;
-  const int w_row_off = (wc * 64 + fr) * 128 + TILE_BYTES;
+  const int w_row_off = (wc * 64 + fr) * 128 + A_BYTES;
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -89,31 +107,43 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
-  stage_tile(srcA, srcW, 0, smem, wave);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nk) stage(t);
 
   for (int kt = 0; kt < nk; ++kt) {
-    char* cur = smem + (kt & 1) * STAGE_BYTES;
-    if (kt + 1 < nk) stage_tile(srcA, srcW, (long)(kt + 1) * BK, smem + ((kt + 1) & 1) * STAGE_BYTES, wave);
+    // tile kt must have landed; the tiles issued after it (up to NST-2 of them) may stay in flight
+    const int ahead = min(nk, kt + NST - 1) - (kt + 1);
+    if (NST == 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+    else if (NST >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + NST - 1 < nk && !(p.ablate & 1)) stage(kt + NST - 1);   // refills the slot every wave finished reading at kt-1
+    const char* cur = smem + (kt % NST) * STAGE;
+    if (p.ablate & 2) continue;
+    s16x8_t af[2][4], wf[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int offk = kk ? offk1 : offk0;
-      s16x8_t af[4], wf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        af[i] = *reinterpret_cast<const s16x8_t*>(cur + a_row_off + i * 2048 + offk);
-        wf[i] = *reinterpret_cast<const s16x8_t*>(cur + w_row_off + i * 2048 + offk);
+        af[kk][i] = *reinterpret_cast<const s16x8_t*>(cur + a_row_off + i * 2048 + offk);
+        wf[kk][i] = *reinterpret_cast<const s16x8_t*>(cur + w_row_off + i * 2048 + offk);
       }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = P::mfma(wf[j], af[i], acc[i][j]);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+        for (int j = 0; j < 4; ++j) acc[i][j] = P::mfma(wf[kk][j], af[kk][i], acc[i][j]);
+    // all 16 LDS reads are issued before the first MFMA: the second half's latency hides under the
+    // first half's MFMAs (the compiler emits counted lgkmcnt waits in issue order)
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
   }
 
+  if (p.ablate & 4) return;
   // ---- epilogue: lane holds out[m][n .. n+3], m = m0+wr*64+i*16+fr, n = n0+wc*64+j*16+4*fg
   const int nbase = n0 + wc * 64 + 4 * fg;
   float4 bj[4];
@@ -133,6 +163,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       orow = (long)frame * (p.n_patches + 1) + 1 + pp;
       posr = p.pos + (long)(1 + pp) * p.N;
       timr = p.time + (long)(frame % p.T) * p.N;
+    }
+    float4 rr[4];
+    if (EPI == GAVA_EPI_F32 && RES) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rr[j] = *reinterpret_cast<const float4*>(p.resid + orow * p.ldr + nbase + j * 16);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -156,10 +191,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
           *reinterpret_cast<uint2*>(o) = pack4<P>(v0, v1, v2, v3);
         }
       } else if (EPI == GAVA_EPI_F32) {
-        if (RES) {
-          const float4 rr = *reinterpret_cast<const float4*>(p.resid + orow * p.ldr + n);
-          v0 += rr.x; v1 += rr.y; v2 += rr.z; v3 += rr.w;
-        }
+        if (RES) { v0 += rr[j].x; v1 += rr[j].y; v2 += rr[j].z; v3 += rr[j].w; }
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) =
             make_float4(v0, v1, v2, v3);
       } else {  // GAVA_EPI_F32_PATCH
@@ -172,27 +204,304 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   }
 }
 
-template <class P>
-int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
-  dim3 grid(gp.n_tiles), block(256);
+template <class P, int BM, int BN, int NST>
+int launch_tile(GemmParams gp, int epi, hipStream_t s) {
+  gp.tiles_m = (gp.M + BM - 1) / BM;
+  gp.tiles_n = gp.N / BN;
+  gp.n_tiles = gp.tiles_m * gp.tiles_n;
+  // super-tile: ~32 concurrent tiles per XCD; keep (sm A-panels + sn W-panels) inside the 4 MiB L2
+  gp.sn = gp.tiles_n < 8 ? gp.tiles_n : 8;
+  gp.sm = 32 / gp.sn < 1 ? 1 : 32 / gp.sn;
+  if (gp.sm > gp.tiles_m) gp.sm = gp.tiles_m;
+  dim3 grid(gp.n_tiles), block((BM / 64) * (BN / 64) * 64);
+#define GAVA_LAUNCH(EPI, RES, SPLIT) \
+  hipLaunchKernelGGL((gemm_kernel<P, EPI, RES, SPLIT, BM, BN, NST>), grid, block, 0, s, gp)
   switch (epi) {
     case GAVA_EPI_H16:
-      if (gp.split_out) hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_H16, false, true>), grid, block, 0, s, gp);
-      else hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_H16, false, false>), grid, block, 0, s, gp);
+      if (gp.split_out) GAVA_LAUNCH(GAVA_EPI_H16, false, true); else GAVA_LAUNCH(GAVA_EPI_H16, false, false);
       break;
     case GAVA_EPI_H16_QGELU:
-      if (gp.split_out) hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_H16_QGELU, false, true>), grid, block, 0, s, gp);
-      else hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_H16_QGELU, false, false>), grid, block, 0, s, gp);
+      if (gp.split_out) GAVA_LAUNCH(GAVA_EPI_H16_QGELU, false, true); else GAVA_LAUNCH(GAVA_EPI_H16_QGELU, false, false);
       break;
     case GAVA_EPI_F32:
-      if (gp.resid) hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_F32, true, false>), grid, block, 0, s, gp);
-      else hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_F32, false, false>), grid, block, 0, s, gp);
+      if (gp.resid) GAVA_LAUNCH(GAVA_EPI_F32, true, false); else GAVA_LAUNCH(GAVA_EPI_F32, false, false);
       break;
-    case GAVA_EPI_F32_PATCH: hipLaunchKernelGGL((gemm_kernel<P, GAVA_EPI_F32_PATCH, false, false>), grid, block, 0, s, gp); break;
+    case GAVA_EPI_F32_PATCH: GAVA_LAUNCH(GAVA_EPI_F32_PATCH, false, false); break;
     default: return GAVA_EINVAL;
   }
+#undef GAVA_LAUNCH
   GAVA_CHECK_LAUNCH();
   return GAVA_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// v3: persistent 256x256 kernel for the big-M GEMMs.
+//   * 8 waves as 2(M) x 4(N), 128x64 outputs per wave (8x4 accumulators = 128 VGPRs); BK = 64,
+//     2 LDS stages of 64 KiB.  Per FLOP it pulls half the operand bytes of the 128^2 tile through
+//     L2->LDS (the measured limiter of v2) and needs 0.375 instead of 0.5 ds_read_b128 per MFMA.
+//   * persistent: gridDim = #CUs; each workgroup walks its XCD's tile range with the k-loop
+//     flattened across tiles, so the first stage of the next tile is already in flight during
+//     the epilogue, and the epilogue's stores drain behind a COUNTED vmcnt while the next tile
+//     computes (nothing waits on them until one k-tile later).
+//   * W rows are read from LDS in a permuted order (row = 16*(fr>>2) + 4*j + (fr&3)) so that the
+//     4 accumulators of an output row hold 16 CONSECUTIVE columns per lane: 32-byte h16 /
+//     64-byte fp32 contiguous per lane, whole 128-byte lines per 4 lanes, no cross-lane shuffles.
+//     The W tile uses its own bank swizzle (bits 1,4,5 of the row) that is conflict-free for
+//     that read pattern.
+template <class P, int EPI, bool RES, bool SPLIT>
+__global__ __launch_bounds__(512, 2)
+void gemm256_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, NW = 8;
+  constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;   // 32 KiB, 64 KiB
+  constexpr int PPW = (BM + BN) / 8 / NW;                            // 8 glds per wave per stage
+  constexpr int NSTORE = (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH) ? 32 : (SPLIT ? 48 : 16);
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // ---- this workgroup's tiles: XCD-contiguous range, strided by the workgroups of the XCD
+  const int nwg = p.n_tiles, nb = gridDim.x;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = nb >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int x_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int x_count = xcd < r ? q + 1 : q;
+  const int my_tiles = slot < x_count ? (x_count - slot + per_xcd - 1) / per_xcd : 0;
+  if (my_tiles == 0) return;
+  const int nk = p.K / BK;
+  const int G = my_tiles * nk;
+
+  auto tile_coords = [&](int j, int& m0, int& n0) {
+    const int wg = x_first + slot + j * per_xcd;
+    const int per_group = p.sm * p.tiles_n;
+    const int g = wg / per_group, first_m = g * p.sm;
+    const int sm = min(p.sm, p.tiles_m - first_m);
+    const int w = wg - g * per_group;
+    const int chunk = w / (sm * p.sn), rr = w - chunk * (sm * p.sn);
+    m0 = (first_m + rr % sm) * BM;
+    n0 = (chunk * p.sn + rr / sm) * BN;
+  };
+
+  const unsigned short* src[PPW];
+  auto set_src = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int piece = wave + i * NW;                 // 0..31: A rows, 32..63: W rows
+      const int row = (piece & 31) * 8 + (lane >> 3);
+      if (i < PPW / 2) {
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        src[i] = p.A + (long)gm * p.lda + chunk * 8;
+      } else {
+        const int chunk = (lane & 7) ^ (((row >> 1) & 1) | (((row >> 4) & 3) << 1));
+        src[i] = p.W + (long)(n0 + row) * p.ldw + chunk * 8;
+      }
+    }
+  };
+  auto stage = [&](int g, int kt) {
+    char* base = smem + (g & 1) * STAGE;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + (long)kt * BK), LDS_PTR(void, base + (wave + i * NW) * 1024), 16, 0, 0);
+  };
+
+  // fragment read offsets.  A rows: wr*128 + i*16 + fr, swizzle (row>>1)&7 = fr>>1.
+  // W rows: wc*64 + 16*(fr>>2) + 4*j + (fr&3), swizzle ((row>>1)&1) | (((row>>4)&3)<<1) = ((fr>>1)&1) | ((fr>>2)<<1)
+  const int swa = fr >> 1;
+  const int swb = ((fr >> 1) & 1) | ((fr >> 2) << 1);
+  const int a_off = (wr * 128 + fr) * 128;
+  const int w_off = A_BYTES + (wc * 64 + 16 * (fr >> 2) + (fr & 3)) * 128;
+  const int a_k0 = (fg ^ swa) << 4, a_k1 = ((4 + fg) ^ swa) << 4;
+  const int w_k0 = (fg ^ swb) << 4, w_k1 = ((4 + fg) ^ swb) << 4;
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  int m0, n0, m0n, n0n;
+  tile_coords(0, m0, n0);
+  set_src(m0, n0);
+  stage(0, 0);
+  bool counted = false;   // the next wait may leave this wave's NSTORE epilogue stores in flight
+
+  for (int j = 0; j < my_tiles; ++j) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int g = j * nk + kt;
+      if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      counted = false;
+      __builtin_amdgcn_s_barrier();
+      if (g + 1 < G) {
+        if (kt + 1 < nk) {
+          if (!(p.ablate & 1)) stage(g + 1, kt + 1);
+        } else {
+          tile_coords(j + 1, m0n, n0n);
+          set_src(m0n, n0n);
+          if (!(p.ablate & 1)) stage(g + 1, 0);
+        }
+      }
+      const char* cur = smem + (g & 1) * STAGE;
+      if (p.ablate & 2) continue;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        s16x8_t wf[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          wf[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 512 + (kk ? w_k1 : w_k0));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const s16x8_t af = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 2048 + (kk ? a_k1 : a_k0));
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[i][jj] = P::mfma(wf[jj], af, acc[i][jj]);
+        }
+      }
+    }
+
+    // ---- epilogue of tile j: lane holds out[m][n .. n+15], m = m0+wr*128+i*16+fr,
+    //      n = n0 + wc*64 + 16*fg + 4*jj + r
+    const int nb0 = n0 + wc * 64 + 16 * fg;
+    float4 bj[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      bj[jj] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb0 + 4 * jj) : make_float4(0, 0, 0, 0);
+    const bool full = m0 + BM <= p.M;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + fr;
+      if (m < p.M && !(p.ablate & 4)) {
+        long orow = m;
+        const float* posr = nullptr;
+        const float* timr = nullptr;
+        if (EPI == GAVA_EPI_F32_PATCH) {
+          const int frame = m / p.n_patches, pp = m - frame * p.n_patches;
+          orow = (long)frame * (p.n_patches + 1) + 1 + pp;
+          posr = p.pos + (long)(1 + pp) * p.N + nb0;
+          timr = p.time + (long)(frame % p.T) * p.N + nb0;
+        }
+        float v[16];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          v[4 * jj + 0] = acc[i][jj][0] + bj[jj].x; v[4 * jj + 1] = acc[i][jj][1] + bj[jj].y;
+          v[4 * jj + 2] = acc[i][jj][2] + bj[jj].z; v[4 * jj + 3] = acc[i][jj][3] + bj[jj].w;
+        }
+        if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU) {
+          if (EPI == GAVA_EPI_H16) {
+            if (nb0 < p.scale_cols) {
+#pragma unroll
+              for (int e = 0; e < 16; ++e) v[e] *= p.scale;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = quick_gelu(v[e]);
+          }
+          unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + nb0;
+          if (SPLIT) {
+            uint2 hi[4], lo[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) split4<P>(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3], hi[jj], lo[jj]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint4 H = make_uint4(hi[2 * h].x, hi[2 * h].y, hi[2 * h + 1].x, hi[2 * h + 1].y);
+              const uint4 L = make_uint4(lo[2 * h].x, lo[2 * h].y, lo[2 * h + 1].x, lo[2 * h + 1].y);
+              *reinterpret_cast<uint4*>(o + 8 * h) = H;
+              *reinterpret_cast<uint4*>(o + p.N + 8 * h) = L;
+              *reinterpret_cast<uint4*>(o + 2 * p.N + 8 * h) = H;
+            }
+          } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint2 x = pack4<P>(v[8 * h], v[8 * h + 1], v[8 * h + 2], v[8 * h + 3]);
+              const uint2 y = pack4<P>(v[8 * h + 4], v[8 * h + 5], v[8 * h + 6], v[8 * h + 7]);
+              *reinterpret_cast<uint4*>(o + 8 * h) = make_uint4(x.x, x.y, y.x, y.y);
+            }
+          }
+        } else {
+          float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + nb0;
+          if (EPI == GAVA_EPI_F32 && RES) {
+            const float* rp = p.resid + orow * p.ldr + nb0;
+            float4 rr[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) rr[jj] = *reinterpret_cast<const float4*>(rp + 4 * jj);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              v[4 * jj] += rr[jj].x; v[4 * jj + 1] += rr[jj].y; v[4 * jj + 2] += rr[jj].z; v[4 * jj + 3] += rr[jj].w;
+            }
+          }
+          if (EPI == GAVA_EPI_F32_PATCH) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const float4 pr = *reinterpret_cast<const float4*>(posr + 4 * jj);
+              const float4 tr = *reinterpret_cast<const float4*>(timr + 4 * jj);
+              v[4 * jj] += pr.x + tr.x; v[4 * jj + 1] += pr.y + tr.y; v[4 * jj + 2] += pr.z + tr.z; v[4 * jj + 3] += pr.w + tr.w;
+            }
+          }
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            *reinterpret_cast<float4*>(o + 4 * jj) = make_float4(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    // a full tile issued exactly NSTORE stores per wave after the in-flight stage: they may stay in
+    // flight over the next wait.  (Ragged tiles store fewer: fall back to vmcnt(0).)
+    counted = full && !(p.ablate & 4);
+    m0 = m0n; n0 = n0n;
+  }
+}
+
+template <class P>
+int launch_256(GemmParams gp, int epi, hipStream_t s) {
+  gp.tiles_m = (gp.M + 255) / 256;
+  gp.tiles_n = gp.N / 256;
+  gp.n_tiles = gp.tiles_m * gp.tiles_n;
+  gp.sn = gp.tiles_n < 4 ? gp.tiles_n : 4;
+  gp.sm = 32 / gp.sn;
+  if (gp.sm > gp.tiles_m) gp.sm = gp.tiles_m;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GAVA_ELAUNCH;
+    n_cu = prop.multiProcessorCount / 8 * 8;
+    if (n_cu <= 0) n_cu = 8;
+  }
+  const int blocks = gp.n_tiles < n_cu ? (gp.n_tiles + 7) / 8 * 8 : n_cu;
+  dim3 grid(blocks), block(512);
+#define GAVA_LAUNCH(EPI, RES, SPLIT) hipLaunchKernelGGL((gemm256_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp)
+  switch (epi) {
+    case GAVA_EPI_H16:
+      if (gp.split_out) GAVA_LAUNCH(GAVA_EPI_H16, false, true); else GAVA_LAUNCH(GAVA_EPI_H16, false, false);
+      break;
+    case GAVA_EPI_H16_QGELU:
+      if (gp.split_out) GAVA_LAUNCH(GAVA_EPI_H16_QGELU, false, true); else GAVA_LAUNCH(GAVA_EPI_H16_QGELU, false, false);
+      break;
+    case GAVA_EPI_F32:
+      if (gp.resid) GAVA_LAUNCH(GAVA_EPI_F32, true, false); else GAVA_LAUNCH(GAVA_EPI_F32, false, false);
+      break;
+    case GAVA_EPI_F32_PATCH: GAVA_LAUNCH(GAVA_EPI_F32_PATCH, false, false); break;
+    default: return GAVA_EINVAL;
+  }
+#undef GAVA_LAUNCH
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+template <class P>
+int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
+  static const int variant = getenv("GAVA_GEMM_VARIANT") ? atoi(getenv("GAVA_GEMM_VARIANT")) : 0;
+  // small-M problems (prompt path, text tower at few classes): 128x128 tiles fill more CUs
+  if (gp.M <= 2048 || variant == 1) return launch_tile<P, 128, 128, 2>(gp, epi, s);
+  if (variant == 2) return launch_tile<P, 256, 128, 3>(gp, epi, s);
+  // measured at M = 100864 (c2): the persistent 256^2 kernel wins for N >= 1536 (qkv 0.48 vs 0.58 ms,
+  // fc1 0.67 vs 0.78 ms); at N = 768 its 1182 tiles quantise badly over 256 workgroups (fc2 0.73 vs 0.68)
+  if (gp.N % 256 == 0 && (gp.N >= 1536 || variant == 3)) return launch_256<P>(gp, epi, s);
+  return launch_tile<P, 128, 128, 2>(gp, epi, s);
 }
 
 }  // namespace
@@ -200,7 +509,7 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
 extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   if (!a || !a->A || !a->W || !a->out) return GAVA_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return GAVA_EINVAL;
-  if (a->N % BN || a->K % BK) return GAVA_EINVAL;
+  if (a->N % 128 || a->K % BK) return GAVA_EINVAL;
   if (a->lda % 8 || a->ldw % 8 || a->lda < a->K || a->ldw < a->K) return GAVA_EINVAL;
   if (((uintptr_t)a->A | (uintptr_t)a->W | (uintptr_t)a->out) & 15) return GAVA_EINVAL;
   if (a->bias && ((uintptr_t)a->bias & 15)) return GAVA_EINVAL;
@@ -218,8 +527,8 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.scale_cols = a->scale_cols; gp.scale = a->scale;
   gp.pos = a->pos; gp.time = a->time; gp.n_patches = a->n_patches; gp.T = a->T;
   gp.split_out = a->split_out;
-  gp.tiles_n = a->N / BN;
-  gp.n_tiles = gp.tiles_n * ((a->M + BM - 1) / BM);
+  static const int ablate = getenv("GAVA_GEMM_ABLATE") ? atoi(getenv("GAVA_GEMM_ABLATE")) : 0;
+  gp.ablate = ablate;
   hipStream_t s = (hipStream_t)stream;
   if (a->prec == GAVA_PREC_F16) return launch_prec<PrecF16>(gp, a->epilogue, s);
   if (a->prec == GAVA_PREC_BF16) return launch_prec<PrecBF16>(gp, a->epilogue, s);

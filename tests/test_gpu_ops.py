@@ -26,7 +26,8 @@ def rnd(shape, scale=1.0, seed=0):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (3, 128, 128), (1000, 384, 768), (257, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (3, 128, 128), (1000, 384, 768), (257, 768, 3072),
+                                   (4100, 768, 768), (2500, 512, 192), (20000, 256, 64), (3000, 384, 128)])
 def test_gemm_epilogues(prec, M, N, K):
     d = dev()
     dt = hip.h16_dtype(prec)
@@ -206,3 +207,32 @@ def test_split_precision_chain(prec, tol):
     ref = (r @ W2.double().t() + b2).float()
     err = float((out - ref).abs().max() / ref.abs().max())
     assert err < tol, err
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_gemm_large_m_patch_split_and_ragged(prec):
+    """The persistent 256x256 kernel (M > 2048, N % 256 == 0): patch epilogue, split output, rows >= M."""
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    frames, n, T, D, K = 200, 16, 4, 256, 192
+    A = rnd((frames * n, K), 1.0, 5).to(d).to(dt)
+    W = rnd((D, K), K ** -0.5, 6).to(d).to(dt)
+    bias, pos, tim = rnd((D,), 1, 7).to(d), rnd((n + 1, D), 1, 8).to(d), rnd((T, D), 1, 9).to(d)
+    X = torch.zeros(frames * (n + 1), D, device=d)
+    hip.gemm(A, W, bias, X, epilogue=hip.EPI_F32_PATCH, prec=prec, pos=pos, time=tim, n_patches=n, T=T)
+    ref = (A.float() @ W.float().t() + bias).view(frames, n, D) + pos[1:].unsqueeze(0) \
+        + tim[torch.arange(frames, device=d) % T].unsqueeze(1)
+    Xv = X.view(frames, n + 1, D)
+    assert torch.allclose(Xv[:, 1:], ref, rtol=1e-4, atol=1e-4)
+    assert torch.all(Xv[:, 0] == 0)
+    # split output + rows beyond M untouched
+    M = 2600
+    A2 = rnd((M, K), 1.0, 15).to(d).to(dt)
+    out = torch.full((M + 300, 3 * D), 3.0, dtype=dt, device=d)
+    hip.gemm(A2, W, bias, out, epilogue=hip.EPI_H16_QGELU, prec=prec, split_out=True, M=M)
+    r = A2.float() @ W.float().t() + bias
+    r = r * torch.sigmoid(1.702 * r)
+    hi, lo = out[:M, :D].float(), out[:M, D:2 * D].float()
+    assert torch.equal(out[:M, :D], out[:M, 2 * D:])
+    assert torch.all(out[M:] == 3.0)
+    assert torch.allclose(hi + lo, r, rtol=3e-5 if prec == hip.PREC_F16 else 3e-4, atol=1e-4)

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Stand-alone launcher for one hot kernel shape (for rocprofv3 --pmc passes and A/B timing).
+
+    python tools/kernel_bench.py fc1|fc2|qkv|out|attn|ln [--iters 5] [--B 64] [--prec fp16]
+"""
+import argparse, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch
+from gava_clip_amd import hip
+from gava_clip_amd.config import VIT_B16_T8 as cfg
+
+ap = argparse.ArgumentParser()
+ap.add_argument("which")
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--B", type=int, default=64)
+ap.add_argument("--prec", default="fp16")
+a = ap.parse_args()
+prec = hip.PREC_NAMES[a.prec]
+dt = hip.h16_dtype(prec)
+d = torch.device("cuda")
+D, F, H, T, G, n1 = cfg.feature_dim, cfg.mlp_dim, cfg.num_heads, cfg.num_frames, cfg.num_global_prompts, cfg.tokens_main
+BT = a.B * T
+R = BT * n1
+g = torch.Generator(device="cuda").manual_seed(1)
+rn = lambda *s, scale=1.0, dtype=dt: (torch.randn(*s, device=d, generator=g) * scale).to(dtype)
+if a.which == "fc1":
+    A, W, b, O = rn(R, D), rn(F, D, scale=D ** -0.5), rn(F, dtype=torch.float32), torch.empty(R, F, dtype=dt, device=d)
+    fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_H16_QGELU, prec=prec); fl = 2.0 * R * F * D
+elif a.which == "fc2":
+    A, W, b, O = rn(R, F), rn(D, F, scale=F ** -0.5), rn(D, dtype=torch.float32), rn(R, D, dtype=torch.float32)
+    fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32, prec=prec, resid=O); fl = 2.0 * R * F * D
+elif a.which == "qkv":
+    A, W, b, O = rn(R, D), rn(3 * D, D, scale=D ** -0.5), rn(3 * D, dtype=torch.float32), torch.empty(R, 3 * D, dtype=dt, device=d)
+    fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_H16, prec=prec, scale_cols=D, scale=0.125); fl = 2.0 * R * 3 * D * D
+elif a.which == "out":
+    A, W, b, O = rn(R, D), rn(D, D, scale=D ** -0.5), rn(D, dtype=torch.float32), rn(R, D, dtype=torch.float32)
+    fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32, prec=prec, resid=O); fl = 2.0 * R * D * D
+elif a.which == "attn":
+    QKV, side, O = rn(R, 3 * D), rn(G + 2 * BT, 2 * D), torch.empty(R, D, dtype=dt, device=d)
+    fn = lambda: hip.attention(QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, batch=BT, heads=H, n_q=n1, n_kmain=n1,
+                               prec=prec, side_k=side[:, :D], side_v=side[:, D:], n_g=G, T=T, has_summary=True)
+    fl = 4.0 * BT * H * n1 * cfg.attn_keys() * 64
+elif a.which == "ln":
+    X, gm, bt, O = rn(R, D, dtype=torch.float32), rn(D, dtype=torch.float32), rn(D, dtype=torch.float32), torch.empty(R, D, dtype=dt, device=d)
+    fn = lambda: hip.layernorm(X, gm, bt, out16=O, prec=prec); fl = 0.0
+else:
+    raise SystemExit("unknown kernel")
+fn(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.iters):
+    fn()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / a.iters
+print(f"{a.which}: {ms:.4f} ms/launch, {fl / ms / 1e9:.1f} TFLOP/s (B={a.B}, {a.prec})")
