@@ -25,53 +25,78 @@ struct AttnParams {
   int batch, heads, n_q, n_kmain, n_g, T, has_summary, n_keys, causal, split;
 };
 
-template <class P, int NKT>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+template <class P, int NKT, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
   constexpr int KP = NKT * 16;
+  constexpr int NIT = (KP * 8 + 255) / 256;          // staging tasks (16 B of K and of V) per thread
   __shared__ __attribute__((aligned(16))) char smem[2 * KP * LDS_ROW];
   char* Ks = smem;
   char* Vs = smem + KP * LDS_ROW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.x / p.heads, h = blockIdx.x - n * p.heads;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n_qt = (p.n_q + 15) >> 4;
 
-  // ---- stage K, V (16 B per lane-task; rows beyond n_keys are zero so that 0 * V stays finite)
-  for (int id = tid; id < KP * 8; id += 256) {
-    const int row = id >> 3, chunk = id & 7;
-    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-    if (row < p.n_keys) {
-      const unsigned short *kr, *vr;
-      if (row < p.n_kmain) {
-        const long off = ((long)n * p.n_kmain + row) * p.ld + h * 64 + chunk * 8;
-        kr = p.k + off; vr = p.v + off;
-      } else {
-        const int s = row - p.n_kmain;
-        long sr;
-        if (s < p.n_g) sr = s;
-        else if (s < p.n_g + p.T) sr = p.n_g + (long)(n / p.T) * p.T + (s - p.n_g);
-        else sr = p.n_g + p.batch + n;
-        const long off = sr * p.lds + h * 64 + chunk * 8;
-        kr = p.sk + off; vr = p.sv + off;
-      }
-      kv = *reinterpret_cast<const uint4*>(kr);
-      vv = *reinterpret_cast<const uint4*>(vr);
+  // ---- Q fragments of this wave's first query tile: in flight while K/V are staged
+  auto q_ptr = [&](int qt) {
+    const int qi = qt * 16 + fr;
+    const int qrow = qi < p.n_q ? qi : p.n_q - 1;
+    return p.q + ((long)n * p.n_q + qrow) * p.ld + h * 64 + 8 * fg;
+  };
+  s16x8_t q0 = {0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0;
+  if (wave < n_qt) {
+    const unsigned short* qp = q_ptr(wave);
+    q0 = *reinterpret_cast<const s16x8_t*>(qp);
+    q1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
+  }
+
+  // ---- stage K, V: branch-free address select, every load issued before the first LDS write.
+  // Rows beyond n_keys are zero so that 0 * V stays finite.
+  {
+    uint4 kv[NIT], vv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int id = tid + it * 256;
+      const int row = id >> 3, chunk = id & 7;
+      const int rowc = row < p.n_keys ? row : 0;
+      const int sidx = rowc - p.n_kmain;                               // >= 0: side row
+      const long sr = sidx < p.n_g ? sidx
+                    : sidx < p.n_g + p.T ? p.n_g + (long)(n / p.T) * p.T + (sidx - p.n_g)
+                                         : (long)p.n_g + p.batch + n;
+      const bool is_main = rowc < p.n_kmain;
+      const long off = (is_main ? ((long)n * p.n_kmain + rowc) * p.ld : sr * p.lds) + h * 64 + chunk * 8;
+      const unsigned short* kb = is_main ? p.k : p.sk;
+      const unsigned short* vb = is_main ? p.v : p.sv;
+      kv[it] = *reinterpret_cast<const uint4*>(kb + off);
+      vv[it] = *reinterpret_cast<const uint4*>(vb + off);
     }
-    *reinterpret_cast<uint4*>(Ks + row * LDS_ROW + chunk * 16) = kv;
-    *reinterpret_cast<uint4*>(Vs + row * LDS_ROW + chunk * 16) = vv;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int id = tid + it * 256;
+      const int row = id >> 3, chunk = id & 7;
+      if (id < KP * 8) {
+        const bool ok = row < p.n_keys;
+        *reinterpret_cast<uint4*>(Ks + row * LDS_ROW + chunk * 16) = ok ? kv[it] : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(Vs + row * LDS_ROW + chunk * 16) = ok ? vv[it] : make_uint4(0, 0, 0, 0);
+      }
+    }
   }
   __syncthreads();
 
-  const int fr = lane & 15, fg = lane >> 4;
-  const int n_qt = (p.n_q + 15) >> 4;
   // transposed-read lane address: lane 4q+pp of a 16-lane group supplies row q, columns 4pp..4pp+3
   const int tr_off = (4 * fg + (fr >> 2)) * LDS_ROW + (fr & 3) * 8;
+  constexpr float LOG2E = 1.4426950408889634f;
 
   for (int qt = wave; qt < n_qt; qt += 4) {
     const int qi = qt * 16 + fr;
-    const int qrow = qi < p.n_q ? qi : p.n_q - 1;
-    const unsigned short* qp = p.q + ((long)n * p.n_q + qrow) * p.ld + h * 64 + 8 * fg;
-    const s16x8_t q0 = *reinterpret_cast<const s16x8_t*>(qp);
-    const s16x8_t q1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
+    // prefetch the next tile's Q while this one computes
+    s16x8_t nq0 = q0, nq1 = q1;
+    if (qt + 4 < n_qt) {
+      const unsigned short* qp = q_ptr(qt + 4);
+      nq0 = *reinterpret_cast<const s16x8_t*>(qp);
+      nq1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
+    }
 
     f32x4_t s[NKT];
 #pragma unroll
@@ -84,31 +109,36 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
       a = P::mfma(k1, q1, a);
       s[kt] = a;
     }
-    // mask + row max (keys of this query are spread over the 4 lanes sharing lane&15)
+    // mask only the key tiles that can hold invalid keys (wave-uniform test), then row max
     float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+      const bool partial = (kt * 16 + 16 > p.n_keys) || (CAUSAL && kt * 16 + 15 > qt * 16);
+      if (partial) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * fg + r;
-        const bool ok = key < p.n_keys && (!p.causal || key <= qi);
-        s[kt][r] = ok ? s[kt][r] : -INFINITY;
-        mx = fmaxf(mx, s[kt][r]);
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * fg + r;
+          const bool ok = key < p.n_keys && (!CAUSAL || key <= qi);
+          s[kt][r] = ok ? s[kt][r] : -INFINITY;
+        }
       }
+      mx = fmaxf(fmaxf(mx, s[kt][0]), fmaxf(s[kt][1], fmaxf(s[kt][2], s[kt][3])));
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mneg = -mx * LOG2E;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = __expf(s[kt][r] - mx);
+        const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], LOG2E, mneg));   // exp(s - mx)
         s[kt][r] = e;
         sum += e;
       }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);
 
     f32x4_t o[4];
 #pragma unroll
@@ -144,6 +174,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         }
       }
     }
+    q0 = nq0; q1 = nq1;
   }
 }
 
@@ -151,11 +182,17 @@ template <class P>
 int launch_attn(const AttnParams& p, hipStream_t s) {
   dim3 grid(p.batch * p.heads), block(256);
   const int tiles = (p.n_keys + 15) / 16;
-  if (tiles <= 2) hipLaunchKernelGGL((attention_kernel<P, 2>), grid, block, 0, s, p);
-  else if (tiles <= 6) hipLaunchKernelGGL((attention_kernel<P, 6>), grid, block, 0, s, p);
-  else if (tiles <= 14) hipLaunchKernelGGL((attention_kernel<P, 14>), grid, block, 0, s, p);
-  else if (tiles <= 20) hipLaunchKernelGGL((attention_kernel<P, 20>), grid, block, 0, s, p);
+#define GAVA_ATTN(N)                                                                              \
+  do {                                                                                            \
+    if (p.causal) hipLaunchKernelGGL((attention_kernel<P, N, true>), grid, block, 0, s, p);       \
+    else hipLaunchKernelGGL((attention_kernel<P, N, false>), grid, block, 0, s, p);               \
+  } while (0)
+  if (tiles <= 2) GAVA_ATTN(2);
+  else if (tiles <= 6) GAVA_ATTN(6);
+  else if (tiles <= 14) GAVA_ATTN(14);
+  else if (tiles <= 20) GAVA_ATTN(20);
   else return GAVA_EINVAL;
+#undef GAVA_ATTN
   GAVA_CHECK_LAUNCH();
   return GAVA_OK;
 }
