@@ -472,8 +472,14 @@ class VitaCLIP(nn.Module):
         if not (self.gather_across_ranks and dist.is_available() and dist.is_initialized()
                 and dist.get_world_size() > 1):
             return feats
+        feats = feats.contiguous()
+        if dist.get_backend() == "gloo" and feats.is_cuda:
+            # CPU rendezvous (tests on a single-GPU box): stage through the host
+            out = torch.empty(dist.get_world_size() * feats.shape[0], feats.shape[1], dtype=feats.dtype)
+            dist.all_gather_into_tensor(out, feats.cpu())
+            return out.to(feats.device)
         out = torch.empty(dist.get_world_size() * feats.shape[0], feats.shape[1], dtype=feats.dtype, device=feats.device)
-        dist.all_gather_into_tensor(out, feats.contiguous())
+        dist.all_gather_into_tensor(out, feats)
         return out
 
     # ---- forward ------------------------------------------------------------------------------

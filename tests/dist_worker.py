@@ -1,0 +1,64 @@
+"""Worker for the multi-process tests: one process per rank, rendezvous on 127.0.0.1."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def gather_cpu(rank, world, port, out_dir):
+    """VitaCLIP._gather on CPU tensors over gloo: rank-major concatenation of whole-clip shards."""
+    from gava_clip_amd import VitaCLIP
+    from gava_clip_amd.config import TINY
+    from helpers import model_kwargs
+    _init(rank, world, port)
+    torch.set_num_threads(1)
+    m = VitaCLIP(**model_kwargs(TINY))
+    feats = torch.arange(3 * 8, dtype=torch.float32).view(3, 8) + 100 * rank
+    got = m._gather(feats)
+    want = torch.cat([torch.arange(3 * 8, dtype=torch.float32).view(3, 8) + 100 * r for r in range(world)])
+    ok = torch.equal(got, want)
+    m.gather_across_ranks = False
+    ok = ok and torch.equal(m._gather(feats), feats)
+    np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.array([int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def sharded_forward_gpu(rank, world, port, out_dir):
+    """Each rank runs whole clips [rank*b,(rank+1)*b) on cuda:0 through the HIP path; logits after the
+    embedding all-gather must equal the single-process logits of the concatenated batch."""
+    from gava_clip_amd import VitaCLIP, synth
+    from gava_clip_amd.config import TINY
+    from helpers import model_kwargs, synth_torch_state
+    _init(rank, world, port)
+    torch.set_num_threads(2)
+    m = VitaCLIP(**model_kwargs(TINY))
+    m.load_state_dict(synth_torch_state(TINY, 3), strict=True)
+    m = m.cuda().eval()
+    b = 2
+    x = torch.from_numpy(synth.synth_clip(b * world, TINY.num_frames, TINY.input_size)).cuda()
+    with torch.no_grad():
+        logits, _, _ = m(x[rank * b:(rank + 1) * b])
+        m.gather_across_ranks = False
+        full, _, _ = m(x)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"sharded{rank}.npy"), logits.cpu().numpy())
+    np.save(os.path.join(out_dir, f"full{rank}.npy"), full.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    fn, rank, world, port, out_dir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    {"gather_cpu": gather_cpu, "sharded_forward_gpu": sharded_forward_gpu}[fn](rank, world, port, out_dir)

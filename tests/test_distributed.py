@@ -1,0 +1,47 @@
+"""Multi-process path (one process per GPU in production, RCCL): covered here with gloo, world_size 2."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(fn, world, tmp_path, timeout=300):
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), fn, str(r), str(world), str(port),
+                               str(tmp_path)], env=env) for r in range(world)]
+    try:
+        codes = [p.wait(timeout=timeout) for p in procs]
+    finally:
+        for p in procs:          # only the exact children this test started
+            if p.poll() is None:
+                p.kill()
+    assert codes == [0] * world
+
+
+def test_gather_gloo_world2(tmp_path):
+    _run("gather_cpu", 2, tmp_path)
+    for r in range(2):
+        assert int(np.load(tmp_path / f"ok{r}.npy")[0]) == 1
+
+
+@pytest.mark.gpu
+def test_sharded_forward_equals_single_process(tmp_path):
+    """2 ranks sharing cuda:0 (gloo rendezvous): gathered logits == logits of the concatenated batch,
+    bit for bit (clips are independent; the head runs on identical gathered embeddings)."""
+    _run("sharded_forward_gpu", 2, tmp_path, timeout=600)
+    full = np.load(tmp_path / "full0.npy")
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"sharded{r}.npy"), full)
+        assert np.array_equal(np.load(tmp_path / f"full{r}.npy"), full)
