@@ -17,10 +17,14 @@
 //     inside it tiles are ordered in SM x SN super-tiles whose operand panels fit that L2.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 constexpr int BK = 64;
+// s_waitcnt immediate for "vmcnt(n) only" on gfx9/CDNA: vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14
+constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
+unsigned long long* g_dbg = nullptr;
 
 struct GemmParams {
   const unsigned short* A; long lda;
@@ -34,6 +38,7 @@ struct GemmParams {
   int tiles_m, tiles_n, n_tiles;
   int split_out;
   int sm, sn;   // super-tile shape (in tiles)
+  unsigned long long* dbg;  // debug only: per-wave segment cycle sums (gava_debug_set_buffer)
   int ablate;   // debug only (GAVA_GEMM_ABLATE): 1 = no staging loads after the prologue, 2 = no LDS reads/MFMA
 };
 
@@ -284,7 +289,7 @@ void gemm256_kernel(const GemmParams p) {
     n0 = (chunk * p.sn + rr / sm) * BN;
   };
 
-  const unsigned short* src[PPW];
+  unsigned src[PPW];   // 32-bit element offsets from p.A / p.W (host guarantees they fit)
   auto set_src = [&](int m0, int n0) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -294,18 +299,20 @@ void gemm256_kernel(const GemmParams p) {
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         int gm = m0 + row;
         gm = gm < p.M ? gm : p.M - 1;
-        src[i] = p.A + (long)gm * p.lda + chunk * 8;
+        src[i] = (unsigned)gm * (unsigned)p.lda + chunk * 8;
       } else {
         const int chunk = (lane & 7) ^ (((row >> 1) & 1) | (((row >> 4) & 3) << 1));
-        src[i] = p.W + (long)(n0 + row) * p.ldw + chunk * 8;
+        src[i] = (unsigned)(n0 + row) * (unsigned)p.ldw + chunk * 8;
       }
     }
   };
+  auto piece = [&](int slot, int kt, int i) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR((i < PPW / 2 ? p.A : p.W) + (size_t)(src[i] + (unsigned)(kt * BK))),
+                                     LDS_PTR(void, smem + slot * STAGE + (wave + i * NW) * 1024), 16, 0, 0);
+  };
   auto stage = [&](int g, int kt) {
-    char* base = smem + (g & 1) * STAGE;
 #pragma unroll
-    for (int i = 0; i < PPW; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + (long)kt * BK), LDS_PTR(void, base + (wave + i * NW) * 1024), 16, 0, 0);
+    for (int i = 0; i < PPW; ++i) piece(g & 1, kt, i);
   };
 
   // fragment read offsets.  A rows: wr*128 + i*16 + fr, swizzle (row>>1)&7 = fr>>1.
@@ -336,30 +343,58 @@ void gemm256_kernel(const GemmParams p) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       counted = false;
       __builtin_amdgcn_s_barrier();
-      if (g + 1 < G) {
-        if (kt + 1 < nk) {
-          if (!(p.ablate & 1)) stage(g + 1, kt + 1);
-        } else {
-          tile_coords(j + 1, m0n, n0n);
-          set_src(m0n, n0n);
-          if (!(p.ablate & 1)) stage(g + 1, 0);
+      // LDS-DMA issue is expensive (~100+ cycles per 1 KiB piece beside running MFMAs): the two waves
+      // that share a SIMD (w and w+4) issue their 8 pieces half an iteration apart, so one of them
+      // always feeds the matrix pipe.  Waves 0-3 issue here, waves 4-7 after the second MFMA group.
+      auto issue_next = [&]() {
+        if (g + 1 < G) {
+          if (kt + 1 < nk) {
+            stage(g + 1, kt + 1);
+          } else {
+            tile_coords(j + 1, m0n, n0n);
+            set_src(m0n, n0n);
+            stage(g + 1, 0);
+          }
         }
-      }
+      };
+      if (wave < 4) issue_next();
       const char* cur = smem + (g & 1) * STAGE;
-      if (p.ablate & 2) continue;
+      s16x8_t wf0[4], wf1[4], a00[4], a01[4], a10[4], a11[4];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        s16x8_t wf[4];
+      for (int jj = 0; jj < 4; ++jj) wf0[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 512 + w_k0);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          wf[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 512 + (kk ? w_k1 : w_k0));
+      for (int i = 0; i < 4; ++i) a00[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 2048 + a_k0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const s16x8_t af = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 2048 + (kk ? a_k1 : a_k0));
+      for (int i = 0; i < 4; ++i) a01[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + (4 + i) * 2048 + a_k0);
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[i][jj] = P::mfma(wf[jj], af, acc[i][jj]);
-        }
-      }
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = P::mfma(wf0[jj], a00[i], acc[i][jj]);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) wf1[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 512 + w_k1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a10[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 2048 + a_k1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[4 + i][jj] = P::mfma(wf0[jj], a01[i], acc[4 + i][jj]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);  // wf0, a00, a01
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // a00 x wf0
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // wf1, a10
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // a01 x wf0
+      if (wave >= 4) issue_next();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a11[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + (4 + i) * 2048 + a_k1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = P::mfma(wf1[jj], a10[i], acc[i][jj]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[4 + i][jj] = P::mfma(wf1[jj], a11[i], acc[4 + i][jj]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);   // a11
+      __builtin_amdgcn_sched_group_barrier(0x008, 32, 1);  // a10 x wf1, a11 x wf1
     }
 
     // ---- epilogue of tile j: lane holds out[m][n .. n+15], m = m0+wr*128+i*16+fr,
@@ -455,7 +490,503 @@ void gemm256_kernel(const GemmParams p) {
   }
 }
 
-template <class P>
+
+// ---------------------------------------------------------------------------------------------
+// v4: v3 with BK = 32 stages in a 4-slot ring (4 x 32 KiB): three stages stay in flight behind
+// counted vmcnt waits, so an L2 miss (~1 us) no longer stalls the tile; one raw s_barrier per
+// 32-deep stage.  Rows are 64 B in LDS; the swizzle is chunk ^ f(g), f = {0,3,2,1}, with
+// g = (row>>2)&3 for the A tile and (row>>4)&3 for the (row-permuted) W tile: conflict-free for
+// every ds_read_b128 lane group of both read patterns.
+template <class P, int EPI, bool RES, bool SPLIT>
+__global__ __launch_bounds__(512, 2)
+void gemm256k32_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, NW = 8, BKS = 32, NSLOT = 4;
+  constexpr int A_BYTES = BM * BKS * 2, STAGE = (BM + BN) * BKS * 2;   // 16 KiB, 32 KiB
+  constexpr int PPW = (BM + BN) / 16 / NW;                             // 4 glds per wave per stage
+  constexpr int NSTORE = (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH) ? 32 : (SPLIT ? 48 : 16);
+  __shared__ __attribute__((aligned(16))) char smem[NSLOT * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  const int nwg = p.n_tiles, nb = gridDim.x;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = nb >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int x_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int x_count = xcd < r ? q + 1 : q;
+  const int my_tiles = slot < x_count ? (x_count - slot + per_xcd - 1) / per_xcd : 0;
+  if (my_tiles == 0) return;
+  const int nk = p.K / BKS;
+  const int G = my_tiles * nk;
+
+  auto tile_coords = [&](int j, int& m0, int& n0) {
+    const int wg = x_first + slot + j * per_xcd;
+    const int per_group = p.sm * p.tiles_n;
+    const int g = wg / per_group, first_m = g * p.sm;
+    const int sm = min(p.sm, p.tiles_m - first_m);
+    const int w = wg - g * per_group;
+    const int chunk = w / (sm * p.sn), rr = w - chunk * (sm * p.sn);
+    m0 = (first_m + rr % sm) * BM;
+    n0 = (chunk * p.sn + rr / sm) * BN;
+  };
+  auto fswz = [](int g) { return (4 - g) & 3; };   // {0,3,2,1}
+
+  const unsigned short* src[PPW];
+  auto set_src = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int piece = wave + i * NW;                 // 0..15: A rows, 16..31: W rows (16 rows each)
+      const int row = (piece & 15) * 16 + (lane >> 2);
+      if (i < PPW / 2) {
+        const int chunk = (lane & 3) ^ fswz((row >> 2) & 3);
+        int gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        src[i] = p.A + (long)gm * p.lda + chunk * 8;
+      } else {
+        const int chunk = (lane & 3) ^ fswz((row >> 4) & 3);
+        src[i] = p.W + (long)(n0 + row) * p.ldw + chunk * 8;
+      }
+    }
+  };
+  // the stage issued for step g goes to slot g & 3; its tile/k offset come from the "load cursor"
+  int ld_kt = 0, ld_j = 0;   // next stage to issue: tile ld_j, k-step ld_kt
+  auto issue_next = [&](int g) {
+    char* base = smem + (g & 3) * STAGE;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + (long)ld_kt * BKS), LDS_PTR(void, base + (wave + i * NW) * 1024), 16, 0, 0);
+    if (++ld_kt == nk) {
+      ld_kt = 0;
+      ++ld_j;
+      if (ld_j < my_tiles) {
+        int mm, nn;
+        tile_coords(ld_j, mm, nn);
+        set_src(mm, nn);
+      }
+    }
+  };
+
+  const int sw = fswz(fr >> 2);
+  const int a_off = (wr * 128 + fr) * 64 + ((fg ^ sw) << 4);
+  const int w_off = A_BYTES + (wc * 64 + 16 * (fr >> 2) + (fr & 3)) * 64 + ((fg ^ sw) << 4);
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  int m0, n0;
+  tile_coords(0, m0, n0);
+  set_src(m0, n0);
+  int issued = 0;
+  for (; issued < 3 && issued < G; ++issued) issue_next(issued);
+  int grace = 0;   // iterations during which this wave's NSTORE epilogue stores may stay in flight
+
+  for (int j = 0; j < my_tiles; ++j) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int g = j * nk + kt;
+      const int ahead = issued - (g + 1);            // stages issued after stage g (0..2)
+      if (ahead == 2) {
+        if (grace > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW + NSTORE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (grace > 0) --grace;
+      __builtin_amdgcn_s_barrier();
+      if (issued < G) { issue_next(issued); ++issued; }
+      const char* cur = smem + (g & 3) * STAGE;
+      s16x8_t wf[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) wf[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 256);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const s16x8_t af = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 1024);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = P::mfma(wf[jj], af, acc[i][jj]);
+      }
+    }
+
+    // ---- epilogue of tile j (same register->output map as v3)
+    const int nb0 = n0 + wc * 64 + 16 * fg;
+    float4 bj[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      bj[jj] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb0 + 4 * jj) : make_float4(0, 0, 0, 0);
+    const bool full = m0 + BM <= p.M;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + fr;
+      if (m < p.M) {
+        long orow = m;
+        const float* posr = nullptr;
+        const float* timr = nullptr;
+        if (EPI == GAVA_EPI_F32_PATCH) {
+          const int frame = m / p.n_patches, pp = m - frame * p.n_patches;
+          orow = (long)frame * (p.n_patches + 1) + 1 + pp;
+          posr = p.pos + (long)(1 + pp) * p.N + nb0;
+          timr = p.time + (long)(frame % p.T) * p.N + nb0;
+        }
+        float v[16];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          v[4 * jj + 0] = acc[i][jj][0] + bj[jj].x; v[4 * jj + 1] = acc[i][jj][1] + bj[jj].y;
+          v[4 * jj + 2] = acc[i][jj][2] + bj[jj].z; v[4 * jj + 3] = acc[i][jj][3] + bj[jj].w;
+        }
+        if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU) {
+          if (EPI == GAVA_EPI_H16) {
+            if (nb0 < p.scale_cols) {
+#pragma unroll
+              for (int e = 0; e < 16; ++e) v[e] *= p.scale;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = quick_gelu(v[e]);
+          }
+          unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + nb0;
+          if (SPLIT) {
+            uint2 hi[4], lo[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) split4<P>(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3], hi[jj], lo[jj]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint4 H = make_uint4(hi[2 * h].x, hi[2 * h].y, hi[2 * h + 1].x, hi[2 * h + 1].y);
+              const uint4 L = make_uint4(lo[2 * h].x, lo[2 * h].y, lo[2 * h + 1].x, lo[2 * h + 1].y);
+              *reinterpret_cast<uint4*>(o + 8 * h) = H;
+              *reinterpret_cast<uint4*>(o + p.N + 8 * h) = L;
+              *reinterpret_cast<uint4*>(o + 2 * p.N + 8 * h) = H;
+            }
+          } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint2 x = pack4<P>(v[8 * h], v[8 * h + 1], v[8 * h + 2], v[8 * h + 3]);
+              const uint2 y = pack4<P>(v[8 * h + 4], v[8 * h + 5], v[8 * h + 6], v[8 * h + 7]);
+              *reinterpret_cast<uint4*>(o + 8 * h) = make_uint4(x.x, x.y, y.x, y.y);
+            }
+          }
+        } else {
+          float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + nb0;
+          if (EPI == GAVA_EPI_F32 && RES) {
+            const float* rp = p.resid + orow * p.ldr + nb0;
+            float4 rr[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) rr[jj] = *reinterpret_cast<const float4*>(rp + 4 * jj);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              v[4 * jj] += rr[jj].x; v[4 * jj + 1] += rr[jj].y; v[4 * jj + 2] += rr[jj].z; v[4 * jj + 3] += rr[jj].w;
+            }
+          }
+          if (EPI == GAVA_EPI_F32_PATCH) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const float4 pr = *reinterpret_cast<const float4*>(posr + 4 * jj);
+              const float4 tr = *reinterpret_cast<const float4*>(timr + 4 * jj);
+              v[4 * jj] += pr.x + tr.x; v[4 * jj + 1] += pr.y + tr.y; v[4 * jj + 2] += pr.z + tr.z; v[4 * jj + 3] += pr.w + tr.w;
+            }
+          }
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            *reinterpret_cast<float4*>(o + 4 * jj) = make_float4(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    // a full tile issued exactly NSTORE stores after the (up to) two stages already in flight: for the
+    // next two waits those stores may stay outstanding; the third wait needs a stage issued after them.
+    grace = full ? 2 : 0;
+    if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (j + 1 < my_tiles) tile_coords(j + 1, m0, n0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// v5 "ping-pong": v4's layout (BK = 32 stages, 4-slot ring) with the two wave groups that share
+// each SIMD (waves 0-3 = rows 0-127, waves 4-7 = rows 128-255 of the tile) running half a stage
+// apart, enforced by two raw s_barriers per stage: while one group issues its 32 MFMAs the other
+// reads its 12 fragments from LDS and issues its 4 LDS-DMA pieces (which cost ~100 issue cycles
+// each beside a running matrix pipe), so the pipe always has exactly one feeder per SIMD.
+// Each wave confirms its OWN pieces one stage ahead (counted vmcnt), and a barrier always
+// separates that confirmation from the other group's reads.  Rows are 64 B in LDS; the swizzle is chunk ^ f(g), f = {0,3,2,1}, with
+// g = (row>>2)&3 for the A tile and (row>>4)&3 for the (row-permuted) W tile: conflict-free for
+// every ds_read_b128 lane group of both read patterns.
+template <class P, int EPI, bool RES, bool SPLIT>
+__global__ __launch_bounds__(512, 2)
+void gemm256pp_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, NW = 8, BKS = 32, NSLOT = 4;
+  constexpr int A_BYTES = BM * BKS * 2, STAGE = (BM + BN) * BKS * 2;   // 16 KiB, 32 KiB
+  constexpr int PPW = (BM + BN) / 16 / NW;                             // 4 glds per wave per stage
+  constexpr int NSTORE = (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH) ? 32 : (SPLIT ? 48 : 16);
+  __shared__ __attribute__((aligned(16))) char smem[NSLOT * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  const int nwg = p.n_tiles, nb = gridDim.x;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = nb >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int x_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int x_count = xcd < r ? q + 1 : q;
+  const int my_tiles = slot < x_count ? (x_count - slot + per_xcd - 1) / per_xcd : 0;
+  if (my_tiles == 0) return;
+  const int nk = p.K / BKS;
+  const int G = my_tiles * nk;
+
+  auto tile_coords = [&](int j, int& m0, int& n0) {
+    const int wg = x_first + slot + j * per_xcd;
+    const int per_group = p.sm * p.tiles_n;
+    const int g = wg / per_group, first_m = g * p.sm;
+    const int sm = min(p.sm, p.tiles_m - first_m);
+    const int w = wg - g * per_group;
+    const int chunk = w / (sm * p.sn), rr = w - chunk * (sm * p.sn);
+    m0 = (first_m + rr % sm) * BM;
+    n0 = (chunk * p.sn + rr / sm) * BN;
+  };
+  auto fswz = [](int g) { return (4 - g) & 3; };   // {0,3,2,1}
+
+  const unsigned short* src[PPW];
+  auto set_src = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int piece = wave + i * NW;                 // 0..15: A rows, 16..31: W rows (16 rows each)
+      const int row = (piece & 15) * 16 + (lane >> 2);
+      if (i < PPW / 2) {
+        const int chunk = (lane & 3) ^ fswz((row >> 2) & 3);
+        int gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        src[i] = p.A + (long)gm * p.lda + chunk * 8;
+      } else {
+        const int chunk = (lane & 3) ^ fswz((row >> 4) & 3);
+        src[i] = p.W + (long)(n0 + row) * p.ldw + chunk * 8;
+      }
+    }
+  };
+  // Load cursor: the next stage to issue is (tile ld_j, k-step ld_kt) -> slot (issued & 3).  Past the
+  // last real stage the same 4 pieces are re-issued from valid addresses into a slot nobody reads
+  // (keeps the loop body branch-free and the vmcnt arithmetic constant); they are drained before exit.
+  int ld_kt = 0, ld_j = 0, issued = 0;
+  // `slot` is a compile-time constant at every call site: with dynamic ring indices hipcc cannot prove
+  // that an in-flight LDS-DMA does not alias the next ds_read and inserts s_waitcnt vmcnt(0) before it,
+  // which silently drains the whole ring every stage.
+  auto issue_piece = [&](int slot, int i) {
+    const int kt_eff = issued < G ? ld_kt : 0;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + (long)kt_eff * BKS),
+                                     LDS_PTR(void, smem + slot * STAGE + (wave + i * NW) * 1024), 16, 0, 0);
+  };
+  auto advance = [&]() {
+    if (issued < G && ++ld_kt == nk) {
+      ld_kt = 0;
+      ++ld_j;
+      if (ld_j < my_tiles) {
+        int mm, nn;
+        tile_coords(ld_j, mm, nn);
+        set_src(mm, nn);
+      }
+    }
+    ++issued;
+  };
+  auto issue_next = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_piece(slot, i);
+    advance();
+  };
+
+  const int sw = fswz(fr >> 2);
+  const int a_off = (wr * 128 + fr) * 64 + ((fg ^ sw) << 4);
+  const int w_off = A_BYTES + (wc * 64 + 16 * (fr >> 2) + (fr & 3)) * 64 + ((fg ^ sw) << 4);
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  int m0, n0;
+  tile_coords(0, m0, n0);
+  set_src(m0, n0);
+  issue_next(0); issue_next(1); issue_next(2);
+  // stage 0 must be visible to everyone before the first reads
+  __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * PPW));
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one segment behind group 0
+  unsigned long long tL = 0, tB1 = 0, tC = 0, tB2 = 0, tE = 0, ts = 0;
+  const bool stamp = p.dbg != nullptr;
+  if (stamp) ts = clock64();
+  int grace = 0;   // load segments during which this wave's NSTORE epilogue stores may stay in flight
+#ifndef GAVA_PP_GLDS_C
+#define GAVA_PP_GLDS_C 2   // LDS-DMA pieces (of 4 per stage) issued inside the MFMA segment
+#endif
+  constexpr int NC = GAVA_PP_GLDS_C, NL = PPW - NC;
+
+  // one 32-deep stage with compile-time ring slot S (host guarantees nk % 4 == 0, so slot = kt & 3)
+  auto stage_body = [&](auto S_, bool closing_barrier) {
+    constexpr int S = decltype(S_)::value;
+    // ---------------- load segment (the other group is in its MFMA segment)
+    // confirm my pieces of stage g+1; the 4 pieces of stage g+2 may stay in flight
+    // (the builtin, not inline asm: hipcc's wait-insertion pass must SEE these counted waits, or it
+    // assumes older LDS-DMAs may still be pending and adds its own vmcnt(0) before the ds_reads)
+    if (grace > 0) __builtin_amdgcn_s_waitcnt(vmcnt_imm(PPW + NSTORE));
+    else __builtin_amdgcn_s_waitcnt(vmcnt_imm(PPW));
+    if (grace > 0) --grace;
+    const char* cur = smem + S * STAGE;
+    s16x8_t wf[4], af[8];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) wf[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 256);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 1024);
+    // stage g+3 -> slot of stage g-1 (both groups finished reading it at least one barrier ago)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) issue_piece((S + 3) & 3, i);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (stamp) { const unsigned long long t = clock64(); tL += t - ts; ts = t; }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (stamp) { const unsigned long long t = clock64(); tB1 += t - ts; ts = t; }
+    // ---------------- MFMA segment (the other group is in its load segment); the remaining pieces
+    // ride in the gaps between MFMAs
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = P::mfma(wf[jj], af[i], acc[i][jj]);
+      if (NC > 0 && (i & 1) == 1 && (i >> 1) < NC) issue_piece((S + 3) & 3, NL + (i >> 1));
+    }
+    if (NC > 0) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 32 - 8 * NC, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    advance();
+    if (stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t = clock64(); tC += t - ts; ts = t; }
+    if (closing_barrier) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (stamp) { const unsigned long long t = clock64(); tB2 += t - ts; ts = t; }
+    }
+  };
+
+  for (int j = 0; j < my_tiles; ++j) {
+    for (int kt = 0; kt < nk; kt += 4) {
+      stage_body(std::integral_constant<int, 0>{}, true);
+      stage_body(std::integral_constant<int, 1>{}, true);
+      stage_body(std::integral_constant<int, 2>{}, true);
+      stage_body(std::integral_constant<int, 3>{}, kt + 4 < nk);   // the tile's last barrier follows the epilogue
+    }
+
+    // ---- epilogue of tile j (same register->output map as v3)
+    const int nb0 = n0 + wc * 64 + 16 * fg;
+    float4 bj[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      bj[jj] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb0 + 4 * jj) : make_float4(0, 0, 0, 0);
+    const bool full = m0 + BM <= p.M;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + fr;
+      if (m < p.M) {
+        long orow = m;
+        const float* posr = nullptr;
+        const float* timr = nullptr;
+        if (EPI == GAVA_EPI_F32_PATCH) {
+          const int frame = m / p.n_patches, pp = m - frame * p.n_patches;
+          orow = (long)frame * (p.n_patches + 1) + 1 + pp;
+          posr = p.pos + (long)(1 + pp) * p.N + nb0;
+          timr = p.time + (long)(frame % p.T) * p.N + nb0;
+        }
+        float v[16];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          v[4 * jj + 0] = acc[i][jj][0] + bj[jj].x; v[4 * jj + 1] = acc[i][jj][1] + bj[jj].y;
+          v[4 * jj + 2] = acc[i][jj][2] + bj[jj].z; v[4 * jj + 3] = acc[i][jj][3] + bj[jj].w;
+        }
+        if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU) {
+          if (EPI == GAVA_EPI_H16) {
+            if (nb0 < p.scale_cols) {
+#pragma unroll
+              for (int e = 0; e < 16; ++e) v[e] *= p.scale;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = quick_gelu(v[e]);
+          }
+          unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + nb0;
+          if (SPLIT) {
+            uint2 hi[4], lo[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) split4<P>(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3], hi[jj], lo[jj]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint4 H = make_uint4(hi[2 * h].x, hi[2 * h].y, hi[2 * h + 1].x, hi[2 * h + 1].y);
+              const uint4 L = make_uint4(lo[2 * h].x, lo[2 * h].y, lo[2 * h + 1].x, lo[2 * h + 1].y);
+              *reinterpret_cast<uint4*>(o + 8 * h) = H;
+              *reinterpret_cast<uint4*>(o + p.N + 8 * h) = L;
+              *reinterpret_cast<uint4*>(o + 2 * p.N + 8 * h) = H;
+            }
+          } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint2 x = pack4<P>(v[8 * h], v[8 * h + 1], v[8 * h + 2], v[8 * h + 3]);
+              const uint2 y = pack4<P>(v[8 * h + 4], v[8 * h + 5], v[8 * h + 6], v[8 * h + 7]);
+              *reinterpret_cast<uint4*>(o + 8 * h) = make_uint4(x.x, x.y, y.x, y.y);
+            }
+          }
+        } else {
+          float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + nb0;
+          if (EPI == GAVA_EPI_F32 && RES) {
+            const float* rp = p.resid + orow * p.ldr + nb0;
+            float4 rr[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) rr[jj] = *reinterpret_cast<const float4*>(rp + 4 * jj);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              v[4 * jj] += rr[jj].x; v[4 * jj + 1] += rr[jj].y; v[4 * jj + 2] += rr[jj].z; v[4 * jj + 3] += rr[jj].w;
+            }
+          }
+          if (EPI == GAVA_EPI_F32_PATCH) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const float4 pr = *reinterpret_cast<const float4*>(posr + 4 * jj);
+              const float4 tr = *reinterpret_cast<const float4*>(timr + 4 * jj);
+              v[4 * jj] += pr.x + tr.x; v[4 * jj + 1] += pr.y + tr.y; v[4 * jj + 2] += pr.z + tr.z; v[4 * jj + 3] += pr.w + tr.w;
+            }
+          }
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            *reinterpret_cast<float4*>(o + 4 * jj) = make_float4(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    // a full tile issued exactly NSTORE stores after the (up to) two stages already in flight: for the
+    // next two waits those stores may stay outstanding; the third wait needs a stage issued after them.
+    grace = full ? 2 : 0;
+    if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (j + 1 < my_tiles) tile_coords(j + 1, m0, n0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (stamp) { const unsigned long long t = clock64(); tE += t - ts; ts = t; }
+    __builtin_amdgcn_s_barrier();               // closes the tile's last MFMA segment (+ epilogue)
+    __builtin_amdgcn_sched_barrier(0);
+    if (stamp) { const unsigned long long t = clock64(); tB2 += t - ts; ts = t; }
+  }
+  if (stamp && lane == 0) {
+    unsigned long long* d = p.dbg + (size_t)(blockIdx.x * 8 + wave) * 8;
+    d[0] = tL; d[1] = tB1; d[2] = tC; d[3] = tB2; d[4] = tE; d[5] = (unsigned long long)G;
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra leading barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy LDS-DMA before the LDS is released
+}
+
+template <class P, int KERN>
 int launch_256(GemmParams gp, int epi, hipStream_t s) {
   gp.tiles_m = (gp.M + 255) / 256;
   gp.tiles_n = gp.N / 256;
@@ -473,7 +1004,12 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
   }
   const int blocks = gp.n_tiles < n_cu ? (gp.n_tiles + 7) / 8 * 8 : n_cu;
   dim3 grid(blocks), block(512);
-#define GAVA_LAUNCH(EPI, RES, SPLIT) hipLaunchKernelGGL((gemm256_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp)
+#define GAVA_LAUNCH(EPI, RES, SPLIT)                                                               \
+  do {                                                                                             \
+    if (KERN == 4) hipLaunchKernelGGL((gemm256k32_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp); \
+    else if (KERN == 5) hipLaunchKernelGGL((gemm256pp_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp); \
+    else hipLaunchKernelGGL((gemm256_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp);         \
+  } while (0)
   switch (epi) {
     case GAVA_EPI_H16:
       if (gp.split_out) GAVA_LAUNCH(GAVA_EPI_H16, false, true); else GAVA_LAUNCH(GAVA_EPI_H16, false, false);
@@ -500,11 +1036,19 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   if (variant == 2) return launch_tile<P, 256, 128, 3>(gp, epi, s);
   // measured at M = 100864 (c2): the persistent 256^2 kernel wins for N >= 1536 (qkv 0.48 vs 0.58 ms,
   // fc1 0.67 vs 0.78 ms); at N = 768 its 1182 tiles quantise badly over 256 workgroups (fc2 0.73 vs 0.68)
-  if (gp.N % 256 == 0 && (gp.N >= 1536 || variant == 3)) return launch_256<P>(gp, epi, s);
+  if (gp.N % 256 == 0 && variant == 4) return launch_256<P, 4>(gp, epi, s);
+  if (gp.N % 256 == 0 && gp.K % 128 == 0 && variant == 5) return launch_256<P, 5>(gp, epi, s);
+  const bool fits32 = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
+  if (gp.N % 256 == 0 && fits32 && (gp.N >= 1536 || variant == 3)) return launch_256<P, 3>(gp, epi, s);
   return launch_tile<P, 128, 128, 2>(gp, epi, s);
 }
 
 }  // namespace
+
+extern "C" int gava_debug_set_buffer(void* dev_u64) {
+  g_dbg = (unsigned long long*)dev_u64;
+  return GAVA_OK;
+}
 
 extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   if (!a || !a->A || !a->W || !a->out) return GAVA_EINVAL;
@@ -529,6 +1073,7 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.split_out = a->split_out;
   static const int ablate = getenv("GAVA_GEMM_ABLATE") ? atoi(getenv("GAVA_GEMM_ABLATE")) : 0;
   gp.ablate = ablate;
+  gp.dbg = g_dbg;
   hipStream_t s = (hipStream_t)stream;
   if (a->prec == GAVA_PREC_F16) return launch_prec<PrecF16>(gp, a->epilogue, s);
   if (a->prec == GAVA_PREC_BF16) return launch_prec<PrecBF16>(gp, a->epilogue, s);

@@ -18,7 +18,7 @@ PREC_TORCH = {PREC_F16: torch.float16, PREC_BF16: torch.bfloat16}
 
 EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_vision_workspace_bytes", "gava_vision_forward", "gava_text_workspace_bytes",
-           "gava_text_forward", "gava_similarity_head", "gava_convert_h16"]
+           "gava_text_forward", "gava_similarity_head", "gava_convert_h16", "gava_debug_set_buffer"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 

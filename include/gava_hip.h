@@ -42,6 +42,9 @@ extern "C" {
 typedef void* gava_stream_t;
 
 int gava_abi_version(void);
+/* Debug hook: device buffer (u64[8] per wave) that instrumented kernels fill with per-segment cycle
+ * sums; NULL (default) disables every stamp.  Not used by the product path. */
+int gava_debug_set_buffer(void* dev_u64);
 
 /* C[M,N] = A[M,K] · W[N,K]^T with a fused epilogue.  Replaces nn.Linear / the conv-as-GEMM of
  * ImagePatchEmbed2D (VitaCLIP_vision_encoder_utils.py:66,79,110-115,215-219;

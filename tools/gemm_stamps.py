@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Per-segment cycle shares of the ping-pong GEMM (v5) from in-kernel s_memtime stamps (diagnostic build path)."""
+import ctypes as C, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+os.environ["GAVA_GEMM_VARIANT"] = "5"
+import torch
+from gava_clip_amd import hip
+lib = hip.load()
+lib.gava_debug_set_buffer.argtypes = [C.c_void_p]
+which = sys.argv[1] if len(sys.argv) > 1 else "fc2"
+R, D, F = 100864, 768, 3072
+g = torch.Generator(device="cuda").manual_seed(1)
+rn = lambda *s, scale=1.0, dtype=torch.float16: (torch.randn(*s, device="cuda", generator=g) * scale).to(dtype)
+if which == "fc2":
+    A, W, b, O = rn(R, F), rn(D, F, scale=F ** -0.5), rn(D, dtype=torch.float32), rn(R, D, dtype=torch.float32)
+    fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32, prec=0, resid=O)
+else:
+    A, W, b, O = rn(R, D), rn(F, D, scale=D ** -0.5), rn(F, dtype=torch.float32), torch.empty(R, F, dtype=torch.float16, device="cuda")
+    fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_H16_QGELU, prec=0)
+for _ in range(10): fn()
+dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device="cuda")
+lib.gava_debug_set_buffer(C.c_void_p(dbg.data_ptr()))
+fn(); torch.cuda.synchronize()
+lib.gava_debug_set_buffer(None)
+d = dbg.view(256, 8, 8).double()
+for grp, name in ((slice(0, 4), "group0 (waves 0-3)"), (slice(4, 8), "group1 (waves 4-7)")):
+    x = d[:, grp].reshape(-1, 8)
+    G = x[:, 5].mean()
+    tot = x[:, :5].sum(1).mean()
+    print(f"{which} {name}: stages/wave {G:.0f}; per stage cycles: load {x[:,0].mean()/G:.0f}  wait-b1 {x[:,1].mean()/G:.0f}  mfma {x[:,2].mean()/G:.0f}  wait-b2 {x[:,3].mean()/G:.0f}  epilogue {x[:,4].mean()/G:.0f}  total {tot/G:.0f}")
