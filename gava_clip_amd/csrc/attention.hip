@@ -23,6 +23,7 @@ struct AttnParams {
   const unsigned short* sk; const unsigned short* sv; long lds;
   unsigned short* out; long ldo;
   int batch, heads, n_q, n_kmain, n_g, T, has_summary, n_keys, causal, split;
+  int qbr; long ldq;
 };
 
 template <class P, int NKT, bool CAUSAL>
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
   auto q_ptr = [&](int qt) {
     const int qi = qt * 16 + fr;
     const int qrow = qi < p.n_q ? qi : p.n_q - 1;
-    return p.q + ((long)n * p.n_q + qrow) * p.ld + h * 64 + 8 * fg;
+    return p.q + ((long)n * p.qbr + qrow) * p.ldq + h * 64 + 8 * fg;
   };
   s16x8_t q0 = {0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0;
   if (wave < n_qt) {
@@ -221,6 +222,9 @@ extern "C" int gava_attention(const gava_attention_args* a, gava_stream_t stream
   p.n_g = a->n_g; p.T = n_side ? a->T : 1; p.has_summary = a->has_summary;
   p.n_keys = a->n_kmain + n_side; p.causal = a->causal; p.split = a->split_out;
   if (a->split_out && a->ld_out < 3 * (int64_t)a->heads * 64) return GAVA_EINVAL;
+  p.qbr = a->q_batch_rows > 0 ? a->q_batch_rows : a->n_q;
+  p.ldq = a->ld_q > 0 ? a->ld_q : a->ld_qkv;
+  if (p.ldq % 8 || p.qbr < a->n_q) return GAVA_EINVAL;
   if (p.n_keys > 320) return GAVA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (a->prec == GAVA_PREC_F16) return launch_attn<PrecF16>(p, s);

@@ -44,6 +44,7 @@ struct VisionWs {
   float* X; void* Xn; void* QKV; void* MIX; void* HID; void* PATCH;
   void* CLS16; float* CP; void* CPn; void* SQKV; void* SMIX; float* SUMM; void* SIDEn; void* SIDEKV;
   void* CLSPOST; float* PROJ;
+  void* XNC; void* QC; void* MIXC; void* HIDC;   // last block: CLS rows only
   size_t total;
 };
 
@@ -71,6 +72,10 @@ VisionWs carve_vision(const gava_vision_model* m, void* ws, size_t cap) {
   w.SIDEKV = c.take(SR * 2 * D * 2);
   w.CLSPOST = c.take(BT * 3 * D * 2);
   w.PROJ = (float*)c.take(BT * E * 4);
+  w.XNC = c.take(BT * D * 2);
+  w.QC = c.take(BT * D * 2);
+  w.MIXC = c.take(BT * D * 2);
+  w.HIDC = c.take(BT * F * 2);
   w.total = (c.off + 255) & ~(size_t)255;
   return w;
 }
@@ -141,22 +146,46 @@ extern "C" int gava_vision_forward(const gava_vision_model* m, const float* x, f
     TRY(gemm(w.SIDEn, D, wqkv + (long)D * D, D, L.b_qkv + D, w.SIDEKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, stream));
     // main path
     TRY(ln(w.X, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
-    TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
-    {
-      gava_attention_args a{};
-      const unsigned short* q = (const unsigned short*)w.QKV;
-      const unsigned short* sk = (const unsigned short*)w.SIDEKV;
-      a.q = q; a.k = q + D; a.v = q + 2 * D; a.ld_qkv = 3 * D;
-      a.side_k = sk; a.side_v = sk + D; a.ld_side = 2 * D;
-      a.out = w.MIX; a.ld_out = D;
-      a.batch = BT; a.heads = m->H; a.n_q = n + 1; a.n_kmain = n + 1;
-      a.n_g = G; a.T = Tm; a.has_summary = 1; a.prec = pr;
-      TRY(gava_attention(&a, stream));
+    const unsigned short* sk = (const unsigned short*)w.SIDEKV;
+    if (i + 1 < m->layers) {
+      TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+      {
+        gava_attention_args a{};
+        const unsigned short* q = (const unsigned short*)w.QKV;
+        a.q = q; a.k = q + D; a.v = q + 2 * D; a.ld_qkv = 3 * D;
+        a.side_k = sk; a.side_v = sk + D; a.ld_side = 2 * D;
+        a.out = w.MIX; a.ld_out = D;
+        a.batch = BT; a.heads = m->H; a.n_q = n + 1; a.n_kmain = n + 1;
+        a.n_g = G; a.T = Tm; a.has_summary = 1; a.prec = pr;
+        TRY(gava_attention(&a, stream));
+      }
+      TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D));
+      TRY(ln(w.X, D, nullptr, L.ln2_g, L.ln2_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
+      TRY(gemm(w.Xn, D, L.w_fc1, D, L.b_fc1, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream));
+      TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D));
+    } else {
+      // Last block: only the CLS row of each frame reaches the outputs (VitaCLIP_vision_encoder.py:126
+      // takes x[:,0]; the summary token comes from the prompt path above).  Keys/values are still
+      // needed for every token, queries / out_proj / MLP only for the B*T CLS rows: same results,
+      // 1/197 of the row work.
+      TRY(gemm(w.Xn, D, wqkv + (long)D * D, D, L.b_qkv + D, (unsigned short*)w.QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream));
+      TRY(gemm(w.Xn, fs, L.w_qkv, D, L.b_qkv, w.QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+      {
+        gava_attention_args a{};
+        const unsigned short* q = (const unsigned short*)w.QKV;
+        a.q = w.QC; a.ld_q = D; a.q_batch_rows = 1;
+        a.k = q + D; a.v = q + 2 * D; a.ld_qkv = 3 * D;
+        a.side_k = sk; a.side_v = sk + D; a.ld_side = 2 * D;
+        a.out = w.MIXC; a.ld_out = D;
+        a.batch = BT; a.heads = m->H; a.n_q = 1; a.n_kmain = n + 1;
+        a.n_g = G; a.T = Tm; a.has_summary = 1; a.prec = pr;
+        TRY(gava_attention(&a, stream));
+      }
+      TRY(gemm(w.MIXC, D, L.w_out, D, L.b_out, w.X, fs, BT, D, D, GAVA_EPI_F32, pr, stream, w.X, fs));
+      TRY(ln(w.X, fs, nullptr, L.ln2_g, L.ln2_b, w.XNC, D, nullptr, 0, BT, D, pr, stream));
+      TRY(gemm(w.XNC, D, L.w_fc1, D, L.b_fc1, w.HIDC, F, BT, F, D, GAVA_EPI_H16_QGELU, pr, stream));
+      TRY(gemm(w.HIDC, F, L.w_fc2, F, L.b_fc2, w.X, fs, BT, D, F, GAVA_EPI_F32, pr, stream, w.X, fs));
     }
-    TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D));
-    TRY(ln(w.X, D, nullptr, L.ln2_g, L.ln2_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
-    TRY(gemm(w.Xn, D, L.w_fc1, D, L.b_fc1, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream));
-    TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D));
     if (debug_cls) TRY(gava::copy_rows(w.X, fs, debug_cls + (long)i * BT * D, BT, D, s));
   }
 

@@ -43,7 +43,8 @@ class AttentionArgs(C.Structure):
                 ("out", _vp), ("ld_out", C.c_int64),
                 ("batch", C.c_int), ("heads", C.c_int), ("n_q", C.c_int), ("n_kmain", C.c_int),
                 ("n_g", C.c_int), ("T", C.c_int), ("has_summary", C.c_int),
-                ("causal", C.c_int), ("prec", C.c_int), ("split_out", C.c_int)]
+                ("causal", C.c_int), ("prec", C.c_int), ("split_out", C.c_int),
+                ("q_batch_rows", C.c_int), ("ld_q", C.c_int64)]
 
 
 class VisionLayer(C.Structure):
@@ -166,7 +167,7 @@ def layernorm(x, gamma, beta, *, out16=None, out32=None, prec, rows=None, in_str
 
 
 def attention(q, k, v, out, *, batch, heads, n_q, n_kmain, prec, causal=False,
-              side_k=None, side_v=None, n_g=0, T=0, has_summary=False, split_out=False):
+              side_k=None, side_v=None, n_g=0, T=0, has_summary=False, split_out=False, q_batch_rows=0):
     a = AttentionArgs()
     a.q, a.k, a.v, a.ld_qkv = ptr(q), ptr(k), ptr(v), q.stride(0)
     a.side_k, a.side_v = ptr(side_k), ptr(side_v)
@@ -175,6 +176,7 @@ def attention(q, k, v, out, *, batch, heads, n_q, n_kmain, prec, causal=False,
     a.batch, a.heads, a.n_q, a.n_kmain = batch, heads, n_q, n_kmain
     a.n_g, a.T, a.has_summary, a.causal, a.prec = n_g, T, int(has_summary), int(causal), prec
     a.split_out = int(split_out)
+    a.q_batch_rows, a.ld_q = q_batch_rows, (q.stride(0) if q_batch_rows else 0)
     check(load().gava_attention(C.byref(a), stream_ptr()), "gava_attention")
 
 

@@ -105,6 +105,10 @@ typedef struct {
   int n_g, T, has_summary;                                       /* side-row structure      */
   int causal, prec;
   int split_out;   /* out row = [hi(heads*64) | lo | hi], see gava_gemm_args */
+  /* optional query addressing (0 = defaults): queries of problem n are rows n*q_batch_rows + [0,n_q)
+   * of q with row stride ld_q.  Defaults: q_batch_rows = n_q, ld_q = ld_qkv.  Lets the last vision
+   * block run only its CLS queries (n_q = 1, q_batch_rows = tokens per frame). */
+  int q_batch_rows; int64_t ld_q;
 } gava_attention_args;
 int gava_attention(const gava_attention_args* a, gava_stream_t stream);
 
