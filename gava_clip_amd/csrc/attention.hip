@@ -13,6 +13,7 @@
 // Vision "side" keys (global/local prompts, summary token) are gathered from a separate small
 // K/V matrix while staging, so prompt tokens are never materialised per frame.
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -24,6 +25,7 @@ struct AttnParams {
   unsigned short* out; long ldo;
   int batch, heads, n_q, n_kmain, n_g, T, has_summary, n_keys, causal, split;
   int qbr; long ldq;
+  unsigned long long* dbg;
 };
 
 template <class P, int NKT, bool CAUSAL>
@@ -38,6 +40,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
   const int n = blockIdx.x / p.heads, h = blockIdx.x - n * p.heads;
   const int fr = lane & 15, fg = lane >> 4;
   const int n_qt = (p.n_q + 15) >> 4;
+  const unsigned long long t_start = p.dbg ? clock64() : 0;
+  unsigned long long t_loads = 0, t_staged = 0;
 
   // ---- Q fragments of this wave's first query tile: in flight while K/V are staged
   auto q_ptr = [&](int qt) {
@@ -72,6 +76,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
       kv[it] = *reinterpret_cast<const uint4*>(kb + off);
       vv[it] = *reinterpret_cast<const uint4*>(vb + off);
     }
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_loads = clock64(); }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int id = tid + it * 256;
@@ -84,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     }
   }
   __syncthreads();
+  if (p.dbg) t_staged = clock64();
 
   // transposed-read lane address: lane 4q+pp of a 16-lane group supplies row q, columns 4pp..4pp+3
   const int tr_off = (4 * fg + (fr >> 2)) * LDS_ROW + (fr & 3) * 8;
@@ -99,16 +105,28 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
       nq1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
     }
 
+    // S^T = K Q^T.  All K fragments of a chunk are requested from LDS before the first MFMA (the
+    // compiler otherwise emits read -> wait -> 2 MFMA per tile and exposes the LDS latency 14 times).
     f32x4_t s[NKT];
+    constexpr int QCH = NKT <= 14 ? NKT : NKT / 2;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const char* kr = Ks + (kt * 16 + fr) * LDS_ROW + fg * 16;
-      const s16x8_t k0 = *reinterpret_cast<const s16x8_t*>(kr);
-      const s16x8_t k1 = *reinterpret_cast<const s16x8_t*>(kr + 64);
-      f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      a = P::mfma(k0, q0, a);
-      a = P::mfma(k1, q1, a);
-      s[kt] = a;
+    for (int c0 = 0; c0 < NKT; c0 += QCH) {
+      s16x8_t kf[QCH][2];
+#pragma unroll
+      for (int t = 0; t < QCH; ++t) {
+        const char* kr = Ks + ((c0 + t) * 16 + fr) * LDS_ROW + fg * 16;
+        kf[t][0] = *reinterpret_cast<const s16x8_t*>(kr);
+        kf[t][1] = *reinterpret_cast<const s16x8_t*>(kr + 64);
+      }
+#pragma unroll
+      for (int t = 0; t < QCH; ++t) {
+        f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        a = P::mfma(kf[t][0], q0, a);
+        a = P::mfma(kf[t][1], q1, a);
+        s[c0 + t] = a;
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * QCH, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * QCH, 0);
     }
     // mask only the key tiles that can hold invalid keys (wave-uniform test), then row max
     float mx = -INFINITY;
@@ -116,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     for (int kt = 0; kt < NKT; ++kt) {
       const bool partial = (kt * 16 + 16 > p.n_keys) || (CAUSAL && kt * 16 + 15 > qt * 16);
       if (partial) {
+        asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch: full tiles skip the masks
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + 4 * fg + r;
@@ -141,22 +160,38 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     sum += __shfl_xor(sum, 32, 64);
     const float inv = __builtin_amdgcn_rcpf(sum);
 
+    // O^T = V^T P^T.  Same idea: every transposed V read of a chunk is in flight before its MFMAs.
     f32x4_t o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    constexpr int NC2 = NKT / 2;                       // 32-key chunks
+    constexpr int PCH = NC2 <= 7 ? NC2 : NC2 / 2;      // chunks per batch
 #pragma unroll
-    for (int c = 0; c < NKT / 2; ++c) {
-      const uint2 lo = pack4<P>(s[2 * c][0], s[2 * c][1], s[2 * c][2], s[2 * c][3]);
-      const uint2 hi = pack4<P>(s[2 * c + 1][0], s[2 * c + 1][1], s[2 * c + 1][2], s[2 * c + 1][3]);
-      const s16x8_t pf = __builtin_bit_cast(s16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
-      const char* vb = Vs + c * 32 * LDS_ROW + tr_off;
+    for (int b0 = 0; b0 < NC2; b0 += PCH) {
+      s16x4_t t0[PCH][4], t1[PCH][4];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const s16x4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + dt * 32));
-        const s16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + 16 * LDS_ROW + dt * 32));
-        const s16x8_t vf = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
-        o[dt] = P::mfma(vf, pf, o[dt]);
+      for (int c = 0; c < PCH; ++c) {
+        const char* vb = Vs + (b0 + c) * 32 * LDS_ROW + tr_off;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          t0[c][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + dt * 32));
+          t1[c][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + 16 * LDS_ROW + dt * 32));
+        }
       }
+#pragma unroll
+      for (int c = 0; c < PCH; ++c) {
+        const int cc = b0 + c;
+        const uint2 lo = pack4<P>(s[2 * cc][0], s[2 * cc][1], s[2 * cc][2], s[2 * cc][3]);
+        const uint2 hi = pack4<P>(s[2 * cc + 1][0], s[2 * cc + 1][1], s[2 * cc + 1][2], s[2 * cc + 1][3]);
+        const s16x8_t pf = __builtin_bit_cast(s16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const s16x8_t vf = __builtin_shufflevector(t0[c][dt], t1[c][dt], 0, 1, 2, 3, 4, 5, 6, 7);
+          o[dt] = P::mfma(vf, pf, o[dt]);
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 8 * PCH, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * PCH, 0);
     }
     if (qi < p.n_q) {
       unsigned short* op = p.out + ((long)n * p.n_q + qi) * p.ldo + h * 64 + 4 * fg;
@@ -176,6 +211,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
       }
     }
     q0 = nq0; q1 = nq1;
+  }
+  if (p.dbg && lane == 0 && blockIdx.x < 4096) {
+    unsigned long long* d = p.dbg + (size_t)(blockIdx.x * 4 + wave) * 4;
+    d[0] = t_loads - t_start; d[1] = t_staged - t_loads; d[2] = clock64() - t_staged; d[3] = (n_qt - wave + 3) / 4;
   }
 }
 
@@ -222,6 +261,7 @@ extern "C" int gava_attention(const gava_attention_args* a, gava_stream_t stream
   p.n_g = a->n_g; p.T = n_side ? a->T : 1; p.has_summary = a->has_summary;
   p.n_keys = a->n_kmain + n_side; p.causal = a->causal; p.split = a->split_out;
   if (a->split_out && a->ld_out < 3 * (int64_t)a->heads * 64) return GAVA_EINVAL;
+  p.dbg = gava::debug_buffer();
   p.qbr = a->q_batch_rows > 0 ? a->q_batch_rows : a->n_q;
   p.ldq = a->ld_q > 0 ? a->ld_q : a->ld_qkv;
   if (p.ldq % 8 || p.qbr < a->n_q) return GAVA_EINVAL;

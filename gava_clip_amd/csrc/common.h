@@ -9,6 +9,9 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -26,6 +29,10 @@ struct PrecF16 {
   static __device__ __forceinline__ float up(unsigned short u) {
     return (float)__builtin_bit_cast(_Float16, u);
   }
+  // two values -> one dword in ONE instruction (v_cvt_pk_f16_f32, round-to-nearest-even)
+  static __device__ __forceinline__ unsigned cvt2(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, f16x2_t));
+  }
 };
 struct PrecBF16 {
   typedef __bf16 T;
@@ -39,23 +46,26 @@ struct PrecBF16 {
   static __device__ __forceinline__ float up(unsigned short u) {
     return __builtin_bit_cast(float, (unsigned)u << 16);
   }
+  static __device__ __forceinline__ unsigned cvt2(float a, float b) {   // v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+  }
 };
 
 template <class P>
 static __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
   uint2 r;
-  r.x = (unsigned)P::cvt(a) | ((unsigned)P::cvt(b) << 16);
-  r.y = (unsigned)P::cvt(c) | ((unsigned)P::cvt(d) << 16);
+  r.x = P::cvt2(a, b);
+  r.y = P::cvt2(c, d);
   return r;
 }
 
 // hi/lo split of 4 values: hi = h16(v), lo = h16(v - hi)
 template <class P>
 static __device__ __forceinline__ void split4(float a, float b, float c, float d, uint2& hi, uint2& lo) {
-  const unsigned short ha = P::cvt(a), hb = P::cvt(b), hc = P::cvt(c), hd = P::cvt(d);
-  hi.x = (unsigned)ha | ((unsigned)hb << 16);
-  hi.y = (unsigned)hc | ((unsigned)hd << 16);
-  lo = pack4<P>(a - P::up(ha), b - P::up(hb), c - P::up(hc), d - P::up(hd));
+  hi.x = P::cvt2(a, b);
+  hi.y = P::cvt2(c, d);
+  lo = pack4<P>(a - P::up((unsigned short)hi.x), b - P::up((unsigned short)(hi.x >> 16)),
+                c - P::up((unsigned short)hi.y), d - P::up((unsigned short)(hi.y >> 16)));
 }
 
 static __device__ __forceinline__ float wave_sum(float v) {

@@ -16,6 +16,7 @@
 //   * workgroup -> tile map: each XCD (private 4 MiB L2) walks a contiguous range of tiles, and
 //     inside it tiles are ordered in SM x SN super-tiles whose operand panels fit that L2.
 #include "common.h"
+#include "internal.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -24,7 +25,6 @@ namespace {
 constexpr int BK = 64;
 // s_waitcnt immediate for "vmcnt(n) only" on gfx9/CDNA: vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14
 constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
-unsigned long long* g_dbg = nullptr;
 
 struct GemmParams {
   const unsigned short* A; long lda;
@@ -1045,11 +1045,6 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int gava_debug_set_buffer(void* dev_u64) {
-  g_dbg = (unsigned long long*)dev_u64;
-  return GAVA_OK;
-}
-
 extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   if (!a || !a->A || !a->W || !a->out) return GAVA_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return GAVA_EINVAL;
@@ -1073,7 +1068,7 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.split_out = a->split_out;
   static const int ablate = getenv("GAVA_GEMM_ABLATE") ? atoi(getenv("GAVA_GEMM_ABLATE")) : 0;
   gp.ablate = ablate;
-  gp.dbg = g_dbg;
+  gp.dbg = gava::debug_buffer();
   hipStream_t s = (hipStream_t)stream;
   if (a->prec == GAVA_PREC_F16) return launch_prec<PrecF16>(gp, a->epilogue, s);
   if (a->prec == GAVA_PREC_BF16) return launch_prec<PrecBF16>(gp, a->epilogue, s);

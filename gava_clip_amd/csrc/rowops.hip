@@ -326,6 +326,15 @@ extern "C" int gava_similarity_head(const float* video, const float* text, const
   return GAVA_OK;
 }
 
+static unsigned long long* g_debug_buffer = nullptr;
+extern "C" int gava_debug_set_buffer(void* dev_u64) {
+  g_debug_buffer = (unsigned long long*)dev_u64;
+  return GAVA_OK;
+}
+namespace gava {
+unsigned long long* debug_buffer() { return g_debug_buffer; }
+}
+
 // ---- internal launchers used by the fused drivers -------------------------------------------
 namespace gava {
 

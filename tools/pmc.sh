@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
-for C in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TA_BUSY_avr TA_BUFFER_TOTAL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_UNALIGNED_STALL"; do
+for C in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_UNALIGNED_STALL"; do
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/tools/kernel_bench.py "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
@@ -17,7 +17,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "gemm_kernel" in k or "attention_kernel" in k or "layernorm_kernel" in k:
+        if "gemm" in k or "attention_kernel" in k or "layernorm_kernel" in k:
             agg[k[:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():
     print(k)
