@@ -492,218 +492,9 @@ void gemm256_kernel(const GemmParams p) {
 
 
 // ---------------------------------------------------------------------------------------------
-// v4: v3 with BK = 32 stages in a 4-slot ring (4 x 32 KiB): three stages stay in flight behind
-// counted vmcnt waits, so an L2 miss (~1 us) no longer stalls the tile; one raw s_barrier per
-// 32-deep stage.  Rows are 64 B in LDS; the swizzle is chunk ^ f(g), f = {0,3,2,1}, with
-// g = (row>>2)&3 for the A tile and (row>>4)&3 for the (row-permuted) W tile: conflict-free for
-// every ds_read_b128 lane group of both read patterns.
-template <class P, int EPI, bool RES, bool SPLIT>
-__global__ __launch_bounds__(512, 2)
-void gemm256k32_kernel(const GemmParams p) {
-  constexpr int BM = 256, BN = 256, NW = 8, BKS = 32, NSLOT = 4;
-  constexpr int A_BYTES = BM * BKS * 2, STAGE = (BM + BN) * BKS * 2;   // 16 KiB, 32 KiB
-  constexpr int PPW = (BM + BN) / 16 / NW;                             // 4 glds per wave per stage
-  constexpr int NSTORE = (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH) ? 32 : (SPLIT ? 48 : 16);
-  __shared__ __attribute__((aligned(16))) char smem[NSLOT * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int fr = lane & 15, fg = lane >> 4;
-
-  const int nwg = p.n_tiles, nb = gridDim.x;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = nb >> 3;
-  const int q = nwg >> 3, r = nwg & 7;
-  const int x_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int x_count = xcd < r ? q + 1 : q;
-  const int my_tiles = slot < x_count ? (x_count - slot + per_xcd - 1) / per_xcd : 0;
-  if (my_tiles == 0) return;
-  const int nk = p.K / BKS;
-  const int G = my_tiles * nk;
-
-  auto tile_coords = [&](int j, int& m0, int& n0) {
-    const int wg = x_first + slot + j * per_xcd;
-    const int per_group = p.sm * p.tiles_n;
-    const int g = wg / per_group, first_m = g * p.sm;
-    const int sm = min(p.sm, p.tiles_m - first_m);
-    const int w = wg - g * per_group;
-    const int chunk = w / (sm * p.sn), rr = w - chunk * (sm * p.sn);
-    m0 = (first_m + rr % sm) * BM;
-    n0 = (chunk * p.sn + rr / sm) * BN;
-  };
-  auto fswz = [](int g) { return (4 - g) & 3; };   // {0,3,2,1}
-
-  const unsigned short* src[PPW];
-  auto set_src = [&](int m0, int n0) {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int piece = wave + i * NW;                 // 0..15: A rows, 16..31: W rows (16 rows each)
-      const int row = (piece & 15) * 16 + (lane >> 2);
-      if (i < PPW / 2) {
-        const int chunk = (lane & 3) ^ fswz((row >> 2) & 3);
-        int gm = m0 + row;
-        gm = gm < p.M ? gm : p.M - 1;
-        src[i] = p.A + (long)gm * p.lda + chunk * 8;
-      } else {
-        const int chunk = (lane & 3) ^ fswz((row >> 4) & 3);
-        src[i] = p.W + (long)(n0 + row) * p.ldw + chunk * 8;
-      }
-    }
-  };
-  // the stage issued for step g goes to slot g & 3; its tile/k offset come from the "load cursor"
-  int ld_kt = 0, ld_j = 0;   // next stage to issue: tile ld_j, k-step ld_kt
-  auto issue_next = [&](int g) {
-    char* base = smem + (g & 3) * STAGE;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + (long)ld_kt * BKS), LDS_PTR(void, base + (wave + i * NW) * 1024), 16, 0, 0);
-    if (++ld_kt == nk) {
-      ld_kt = 0;
-      ++ld_j;
-      if (ld_j < my_tiles) {
-        int mm, nn;
-        tile_coords(ld_j, mm, nn);
-        set_src(mm, nn);
-      }
-    }
-  };
-
-  const int sw = fswz(fr >> 2);
-  const int a_off = (wr * 128 + fr) * 64 + ((fg ^ sw) << 4);
-  const int w_off = A_BYTES + (wc * 64 + 16 * (fr >> 2) + (fr & 3)) * 64 + ((fg ^ sw) << 4);
-
-  f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  int m0, n0;
-  tile_coords(0, m0, n0);
-  set_src(m0, n0);
-  int issued = 0;
-  for (; issued < 3 && issued < G; ++issued) issue_next(issued);
-  int grace = 0;   // iterations during which this wave's NSTORE epilogue stores may stay in flight
-
-  for (int j = 0; j < my_tiles; ++j) {
-    for (int kt = 0; kt < nk; ++kt) {
-      const int g = j * nk + kt;
-      const int ahead = issued - (g + 1);            // stages issued after stage g (0..2)
-      if (ahead == 2) {
-        if (grace > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW + NSTORE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      if (grace > 0) --grace;
-      __builtin_amdgcn_s_barrier();
-      if (issued < G) { issue_next(issued); ++issued; }
-      const char* cur = smem + (g & 3) * STAGE;
-      s16x8_t wf[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) wf[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 256);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const s16x8_t af = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 1024);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = P::mfma(wf[jj], af, acc[i][jj]);
-      }
-    }
-
-    // ---- epilogue of tile j (same register->output map as v3)
-    const int nb0 = n0 + wc * 64 + 16 * fg;
-    float4 bj[4];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-      bj[jj] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb0 + 4 * jj) : make_float4(0, 0, 0, 0);
-    const bool full = m0 + BM <= p.M;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wr * 128 + i * 16 + fr;
-      if (m < p.M) {
-        long orow = m;
-        const float* posr = nullptr;
-        const float* timr = nullptr;
-        if (EPI == GAVA_EPI_F32_PATCH) {
-          const int frame = m / p.n_patches, pp = m - frame * p.n_patches;
-          orow = (long)frame * (p.n_patches + 1) + 1 + pp;
-          posr = p.pos + (long)(1 + pp) * p.N + nb0;
-          timr = p.time + (long)(frame % p.T) * p.N + nb0;
-        }
-        float v[16];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          v[4 * jj + 0] = acc[i][jj][0] + bj[jj].x; v[4 * jj + 1] = acc[i][jj][1] + bj[jj].y;
-          v[4 * jj + 2] = acc[i][jj][2] + bj[jj].z; v[4 * jj + 3] = acc[i][jj][3] + bj[jj].w;
-        }
-        if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU) {
-          if (EPI == GAVA_EPI_H16) {
-            if (nb0 < p.scale_cols) {
-#pragma unroll
-              for (int e = 0; e < 16; ++e) v[e] *= p.scale;
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = quick_gelu(v[e]);
-          }
-          unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + nb0;
-          if (SPLIT) {
-            uint2 hi[4], lo[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) split4<P>(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3], hi[jj], lo[jj]);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const uint4 H = make_uint4(hi[2 * h].x, hi[2 * h].y, hi[2 * h + 1].x, hi[2 * h + 1].y);
-              const uint4 L = make_uint4(lo[2 * h].x, lo[2 * h].y, lo[2 * h + 1].x, lo[2 * h + 1].y);
-              *reinterpret_cast<uint4*>(o + 8 * h) = H;
-              *reinterpret_cast<uint4*>(o + p.N + 8 * h) = L;
-              *reinterpret_cast<uint4*>(o + 2 * p.N + 8 * h) = H;
-            }
-          } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const uint2 x = pack4<P>(v[8 * h], v[8 * h + 1], v[8 * h + 2], v[8 * h + 3]);
-              const uint2 y = pack4<P>(v[8 * h + 4], v[8 * h + 5], v[8 * h + 6], v[8 * h + 7]);
-              *reinterpret_cast<uint4*>(o + 8 * h) = make_uint4(x.x, x.y, y.x, y.y);
-            }
-          }
-        } else {
-          float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + nb0;
-          if (EPI == GAVA_EPI_F32 && RES) {
-            const float* rp = p.resid + orow * p.ldr + nb0;
-            float4 rr[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) rr[jj] = *reinterpret_cast<const float4*>(rp + 4 * jj);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              v[4 * jj] += rr[jj].x; v[4 * jj + 1] += rr[jj].y; v[4 * jj + 2] += rr[jj].z; v[4 * jj + 3] += rr[jj].w;
-            }
-          }
-          if (EPI == GAVA_EPI_F32_PATCH) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              const float4 pr = *reinterpret_cast<const float4*>(posr + 4 * jj);
-              const float4 tr = *reinterpret_cast<const float4*>(timr + 4 * jj);
-              v[4 * jj] += pr.x + tr.x; v[4 * jj + 1] += pr.y + tr.y; v[4 * jj + 2] += pr.z + tr.z; v[4 * jj + 3] += pr.w + tr.w;
-            }
-          }
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-            *reinterpret_cast<float4*>(o + 4 * jj) = make_float4(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
-        }
-      }
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
-    // a full tile issued exactly NSTORE stores after the (up to) two stages already in flight: for the
-    // next two waits those stores may stay outstanding; the third wait needs a stage issued after them.
-    grace = full ? 2 : 0;
-    if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (j + 1 < my_tiles) tile_coords(j + 1, m0, n0);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// v5 "ping-pong": v4's layout (BK = 32 stages, 4-slot ring) with the two wave groups that share
+// v5 "ping-pong" (EXPERIMENTAL, GAVA_GEMM_VARIANT=5): BK = 32 stages in a 4-slot ring (4 x 32 KiB,
+// 64-byte LDS rows, swizzle chunk ^ {0,3,2,1}[g], g = (row>>2)&3 for A and (row>>4)&3 for the
+// row-permuted W tile) with the two wave groups that share
 // each SIMD (waves 0-3 = rows 0-127, waves 4-7 = rows 128-255 of the tile) running half a stage
 // apart, enforced by two raw s_barriers per stage: while one group issues its 32 MFMAs the other
 // reads its 12 fragments from LDS and issues its 4 LDS-DMA pieces (which cost ~100 issue cycles
@@ -1006,8 +797,7 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
   dim3 grid(blocks), block(512);
 #define GAVA_LAUNCH(EPI, RES, SPLIT)                                                               \
   do {                                                                                             \
-    if (KERN == 4) hipLaunchKernelGGL((gemm256k32_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp); \
-    else if (KERN == 5) hipLaunchKernelGGL((gemm256pp_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp); \
+    if (KERN == 5) hipLaunchKernelGGL((gemm256pp_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp); \
     else hipLaunchKernelGGL((gemm256_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp);         \
   } while (0)
   switch (epi) {
@@ -1028,6 +818,7 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
   return GAVA_OK;
 }
 
+
 template <class P>
 int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   static const int variant = getenv("GAVA_GEMM_VARIANT") ? atoi(getenv("GAVA_GEMM_VARIANT")) : 0;
@@ -1036,7 +827,6 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   if (variant == 2) return launch_tile<P, 256, 128, 3>(gp, epi, s);
   // measured at M = 100864 (c2): the persistent 256^2 kernel wins for N >= 1536 (qkv 0.48 vs 0.58 ms,
   // fc1 0.67 vs 0.78 ms); at N = 768 its 1182 tiles quantise badly over 256 workgroups (fc2 0.73 vs 0.68)
-  if (gp.N % 256 == 0 && variant == 4) return launch_256<P, 4>(gp, epi, s);
   if (gp.N % 256 == 0 && gp.K % 128 == 0 && variant == 5) return launch_256<P, 5>(gp, epi, s);
   const bool fits32 = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
   if (gp.N % 256 == 0 && fits32 && (gp.N >= 1536 || variant == 3)) return launch_256<P, 3>(gp, epi, s);

@@ -127,3 +127,29 @@ def test_text_400_classes_matches_oracle():
     o = Oracle(cfg, sd, torch.cat(m.tokenized_prompts))
     want = o.text(o.prompts())
     assert rel_to_max(tf.cpu().numpy(), want.numpy()) < 3e-3
+
+
+@pytest.mark.parametrize("name,cfg,B", [
+    # config c5's shapes at reduced depth: P=14 (patch K=588 padded to 640), 257 tokens/frame, D=1024, 16 heads,
+    # T=32 -> 298 attention keys (20 key tiles), text width 768 / 12 heads, E=768
+    ("vit_l14_t32", VitaConfig(num_frames=32, feature_dim=1024, patch_size=14, num_heads=16, num_layers=2,
+                               embed_dim=768, text_width=768, text_heads=12, text_layers=2), 1),
+    # config c3's vision shapes at reduced depth: T=16 -> 222 attention keys
+    ("vit_b16_t16", VitaConfig(num_frames=16, num_layers=2, text_layers=2), 2),
+])
+def test_other_baseline_shapes_vs_oracle(name, cfg, B):
+    m, sd = build(cfg)
+    x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size, seed=11))
+    with torch.no_grad():
+        logits, _, _ = m(x.cuda())
+    o = Oracle(cfg, sd, torch.cat(m.tokenized_prompts)).forward(x, trace=True)
+    e = rel_to_max(logits.cpu().numpy(), o["logits"].numpy())
+    cls = m.last["cls_rows"].cpu().numpy()
+    per_layer = [rel_to_max(cls[i], o["trace"][f"block{i}"][:, 0].numpy()) for i in range(cfg.num_layers)]
+    print(f"\n[{name}] logits rel-to-max {e:.3e}; cls rows per layer {['%.1e' % v for v in per_layer]}; "
+          f"video {rel_to_max(m.last['video_features'].cpu().numpy(), o['video_features'].numpy()):.2e}")
+    assert max(per_layer) < 3e-3
+    assert rel_to_max(m.last["summary"].cpu().numpy(), o["summary"].numpy()) < 3e-3
+    # shallow random nets give small, noisy logits: bound at 2e-3 here (measured 1.0e-3 / 5e-4); the 1e-3
+    # criterion is enforced on the full-depth golden config c1 above
+    assert e < 2e-3
