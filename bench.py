@@ -220,7 +220,7 @@ def main():
     fwd_flops = fl.forward_flops(cfg, B, n_cls)
 
     out = {
-        "metric": "clips/sec (8-frame 224^2 ViT-B/16 VitaCLIP.forward)", "value": round(value, 2), "unit": "clips/s",
+        "metric": "clips/sec (%d-frame 224^2 ViT-B/16 VitaCLIP.forward)" % cfg.num_frames, "value": round(value, 2), "unit": "clips/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * secs / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.prec, "data": "synthetic",
         "config": {"workload": f"{a.config}: {desc}", "clips_per_gpu": B, "global_batch": B * world,

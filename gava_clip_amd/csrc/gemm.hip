@@ -105,16 +105,30 @@ void gemm_kernel(const GemmParams p) {
   const int a_row_off = (wr * 64 + fr) * 128;
   const int w_row_off = (wc * 64 + fr) * 128 + A_BYTES;
 
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
   const int nk = p.K / BK;
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
     if (t < nk) stage(t);
+
+  // Accumulators start at the residual tile (out = resid + A W^T accumulates in fp32 on top of it): the
+  // residual read is in flight while the first operand stage lands, instead of being a serialised
+  // load -> add -> store chain in the epilogue when every register still holds an accumulator.
+  f32x4_t acc[4][4];
+  if (EPI == GAVA_EPI_F32 && RES) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m = m0 + wr * 64 + i * 16 + fr;
+      m = m < p.M ? m : p.M - 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = *reinterpret_cast<const f32x4_t*>(p.resid + (long)m * p.ldr + n0 + wc * 64 + 4 * fg + j * 16);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
 
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt must have landed; the tiles issued after it (up to NST-2 of them) may stay in flight
@@ -169,11 +183,6 @@ void gemm_kernel(const GemmParams p) {
       posr = p.pos + (long)(1 + pp) * p.N;
       timr = p.time + (long)(frame % p.T) * p.N;
     }
-    float4 rr[4];
-    if (EPI == GAVA_EPI_F32 && RES) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) rr[j] = *reinterpret_cast<const float4*>(p.resid + orow * p.ldr + nbase + j * 16);
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = nbase + j * 16;
@@ -196,7 +205,6 @@ void gemm_kernel(const GemmParams p) {
           *reinterpret_cast<uint2*>(o) = pack4<P>(v0, v1, v2, v3);
         }
       } else if (EPI == GAVA_EPI_F32) {
-        if (RES) { v0 += rr[j].x; v1 += rr[j].y; v2 += rr[j].z; v3 += rr[j].w; }
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) =
             make_float4(v0, v1, v2, v3);
       } else {  // GAVA_EPI_F32_PATCH
@@ -330,6 +338,14 @@ void gemm256_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  // De-phase the workgroups of an XCD (GAVA_GEMM_ABLATE bit 16, experiment): persistent workgroups with
+  // equal tiles run in lockstep, so all 32 of an XCD store their tiles (32 x 128 KiB = the whole 4 MiB
+  // L2) at the same moment and the stores drain at HBM speed while every wave waits on the in-order
+  // vmcnt.  Spread over one tile time, each burst fits in L2.
+  if (p.ablate & 16) {
+    const long delay = (long)slot * nk * 2500 / per_xcd;     // cycles; one tile ~ nk * 2500
+    for (long d = 0; d < delay; d += 8128) __builtin_amdgcn_s_sleep(127);
+  }
   int m0, n0, m0n, n0n;
   tile_coords(0, m0, n0);
   set_src(m0, n0);
@@ -666,11 +682,16 @@ void gemm256pp_kernel(const GemmParams p) {
   };
 
   for (int j = 0; j < my_tiles; ++j) {
-    for (int kt = 0; kt < nk; kt += 4) {
-      stage_body(std::integral_constant<int, 0>{}, true);
-      stage_body(std::integral_constant<int, 1>{}, true);
-      stage_body(std::integral_constant<int, 2>{}, true);
-      stage_body(std::integral_constant<int, 3>{}, kt + 4 < nk);   // the tile's last barrier follows the epilogue
+    // 12 stages per trip: hipcc still drains the ring (vmcnt(0)) once at the top of the loop body, where its
+    // wait-insertion pass merges the back edge conservatively; once per 12 stages is cheap.
+    for (int kt = 0; kt < nk; kt += 12) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        stage_body(std::integral_constant<int, 0>{}, true);
+        stage_body(std::integral_constant<int, 1>{}, true);
+        stage_body(std::integral_constant<int, 2>{}, true);
+        stage_body(std::integral_constant<int, 3>{}, u < 2 || kt + 12 < nk);   // the tile's last barrier follows the epilogue
+      }
     }
 
     // ---- epilogue of tile j (same register->output map as v3)
@@ -683,7 +704,7 @@ void gemm256pp_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int m = m0 + wr * 128 + i * 16 + fr;
-      if (m < p.M) {
+      if (m < p.M && !(p.ablate & 4)) {
         long orow = m;
         const float* posr = nullptr;
         const float* timr = nullptr;
@@ -760,7 +781,7 @@ void gemm256pp_kernel(const GemmParams p) {
     }
     // a full tile issued exactly NSTORE stores after the (up to) two stages already in flight: for the
     // next two waits those stores may stay outstanding; the third wait needs a stage issued after them.
-    grace = full ? 2 : 0;
+    grace = (full && !(p.ablate & 4)) ? 2 : 0;
     if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (j + 1 < my_tiles) tile_coords(j + 1, m0, n0);
     __builtin_amdgcn_sched_barrier(0);
@@ -827,7 +848,7 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   if (variant == 2) return launch_tile<P, 256, 128, 3>(gp, epi, s);
   // measured at M = 100864 (c2): the persistent 256^2 kernel wins for N >= 1536 (qkv 0.48 vs 0.58 ms,
   // fc1 0.67 vs 0.78 ms); at N = 768 its 1182 tiles quantise badly over 256 workgroups (fc2 0.73 vs 0.68)
-  if (gp.N % 256 == 0 && gp.K % 128 == 0 && variant == 5) return launch_256<P, 5>(gp, epi, s);
+  if (gp.N % 256 == 0 && gp.K % 384 == 0 && variant == 5) return launch_256<P, 5>(gp, epi, s);
   const bool fits32 = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
   if (gp.N % 256 == 0 && fits32 && (gp.N >= 1536 || variant == 3)) return launch_256<P, 3>(gp, epi, s);
   return launch_tile<P, 128, 128, 2>(gp, epi, s);

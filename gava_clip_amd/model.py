@@ -309,6 +309,10 @@ class VitaCLIP(nn.Module):
         # text tower GEMMs in split precision (hi+lo operands, 3 MFMA passes): the text side is <1 % of
         # the work at the headline configs but dominates the logits error at plain 16-bit operands
         self.text_split_precision = os.environ.get("GAVA_TEXT_SPLIT", "1") != "0"
+        # eval-time text-feature cache: in eval mode the text tower is input
+        # independent; opt-in because a benchmark must not skip work.  Invalidated by any parameter update.
+        self.cache_text_features = False
+        self._text_cache = None
         self.gather_across_ranks = True     # RCCL all-gather of clip embeddings when world_size > 1
         self.debug_taps = False             # keep per-layer CLS rows of the last forward
         self._shape = dict(size=input_size[0], P=patch_size[0], D=feature_dim, H=num_heads, layers=num_layers,
@@ -492,7 +496,12 @@ class VitaCLIP(nn.Module):
         if self.use_text_prompt_learning:
             if desc_wise:
                 assert self.training == False
-            text = self.encode_text()
+            key = self._pack_key() if (self.cache_text_features and not self.training) else None
+            if key is not None and self._text_cache is not None and self._text_cache[0] == key:
+                text = self._text_cache[1]
+            else:
+                text = self.encode_text()
+                self._text_cache = (key, text) if key is not None else None
         else:
             text = self.text_features.to(device=x.device, dtype=torch.float32).contiguous()
         Bg, Cn = video.shape[0], text.shape[0]

@@ -153,3 +153,20 @@ def test_other_baseline_shapes_vs_oracle(name, cfg, B):
     # shallow random nets give small, noisy logits: bound at 2e-3 here (measured 1.0e-3 / 5e-4); the 1e-3
     # criterion is enforced on the full-depth golden config c1 above
     assert e < 2e-3
+
+
+def test_eval_text_feature_cache_is_exact_and_invalidated():
+    m, sd = build(TINY)
+    x = torch.from_numpy(synth.synth_clip(2, TINY.num_frames, TINY.input_size)).cuda()
+    with torch.no_grad():
+        ref, _, _ = m(x)
+        m.cache_text_features = True
+        a, _, _ = m(x)
+        b, _, _ = m(x)                       # served from the cache
+        assert torch.equal(ref, a) and torch.equal(a, b) and m._text_cache is not None
+        m.prompt_learner.ctx.add_(0.05)      # parameter update -> cache key changes
+        c, _, _ = m(x)
+        assert not torch.equal(a, c)
+        m.train()
+        m(x)
+        assert m._text_cache is None
