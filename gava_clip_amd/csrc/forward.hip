@@ -114,10 +114,11 @@ extern "C" int gava_vision_forward(const gava_vision_model* m, const float* x, f
   const char* h16 = nullptr; (void)h16;
 
   // ---- embedding (VitaCLIP_vision_encoder.py:105-113)
-  TRY(gava::patch_gather(x, w.PATCH, m->B, m->T_in, m->size, m->P, Kp, pr, s));
   {
+    // im2col-free patch embedding: the GEMM builds its A tiles straight from the frames
     gava_gemm_args a{};
-    a.A = w.PATCH; a.lda = Kp; a.W = m->w_patch; a.ldw = Kp; a.bias = m->b_patch;
+    a.A = nullptr; a.lda = Kp; a.frames = x; a.frame_size = m->size; a.patch = m->P;
+    a.W = m->w_patch; a.ldw = Kp; a.bias = m->b_patch;
     a.out = w.X; a.ldo = D; a.M = BT * n; a.N = D; a.K = Kp; a.epilogue = GAVA_EPI_F32_PATCH; a.prec = pr;
     a.pos = m->pos_embed; a.time = m->time_embed; a.n_patches = n; a.T = m->T_in;
     TRY(gava_gemm(&a, stream));

@@ -35,6 +35,7 @@ struct GemmParams {
   int M, N, K;
   int scale_cols; float scale;
   const float* pos; const float* time; int n_patches; int T;
+  const float* frames; int fsize; int patch;   // im2col-free patch A operand (EPI_F32_PATCH, A == nullptr)
   int tiles_m, tiles_n, n_tiles;
   int split_out;
   int sm, sn;   // super-tile shape (in tiles)
@@ -76,6 +77,7 @@ void gemm_kernel(const GemmParams p) {
   }
   const int m0 = mt * BM, n0 = nt * BN;
 
+  const bool direct = EPI == GAVA_EPI_F32_PATCH && p.frames != nullptr;
   // ---- per-lane source pointers of this wave's staging pieces (swizzle on the source side)
   const unsigned short* src[PPW];
 #pragma unroll
@@ -86,7 +88,7 @@ void gemm_kernel(const GemmParams p) {
     if (piece < BM / 8) {
       int gm = m0 + row;
       gm = gm < p.M ? gm : p.M - 1;
-      src[i] = p.A + (long)gm * p.lda + chunk * 8;
+      src[i] = direct ? p.W : p.A + (long)gm * p.lda + chunk * 8;   // unused in direct mode
     } else {
       src[i] = p.W + (long)(n0 + row - BM) * p.ldw + chunk * 8;
     }
@@ -94,8 +96,59 @@ void gemm_kernel(const GemmParams p) {
   auto stage = [&](int kt) {
     char* base = smem + (kt % NST) * STAGE;
 #pragma unroll
-    for (int i = 0; i < PPW; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + (long)kt * BK), LDS_PTR(void, base + (wave + i * NW) * 1024), 16, 0, 0);
+    for (int i = 0; i < PPW; ++i) {
+      const int piece = wave + i * NW;
+      if (direct && piece < BM / 8) continue;     // A tile comes from stage_patch_a()
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + (long)kt * BK), LDS_PTR(void, base + piece * 1024), 16, 0, 0);
+    }
+  };
+  // im2col-free patch operand: task = (row of the A tile, 16-byte chunk of 8 consecutive k).  k = (c,ky,kx);
+  // for P % 8 == 0 a chunk is 8 consecutive pixels of one image row: two coalesced float4 loads.
+  // Split staging (issue early / write late): patch_load() puts the global loads in flight before the MFMAs
+  // of the current k-tile, patch_write() converts and writes the LDS tile after them.
+  constexpr int NTASK = BM * 8 / (NW * 64);
+  float pe[NTASK][8];
+  auto patch_load = [&](int kt) {
+    const int P2 = p.patch * p.patch, Kreal = 3 * P2, g = p.fsize / p.patch;
+#pragma unroll
+    for (int ti = 0; ti < NTASK; ++ti) {
+      const int task = tid + ti * NW * 64;
+      const int row = task >> 3, chunk = task & 7;
+      int m = m0 + row;
+      m = m < p.M ? m : p.M - 1;
+      const int frame = m / p.n_patches, pp = m - frame * p.n_patches;
+      const int b = frame / p.T, t = frame - b * p.T;
+      const int py = pp / g, px = pp - py * g;
+      const int k = kt * BK + chunk * 8;
+      if ((p.patch & 7) == 0 && k + 8 <= Kreal) {
+        const int c = k / P2, rem = k - c * P2, ky = rem / p.patch, kx = rem - ky * p.patch;
+        const float* sp = p.frames + ((((long)b * 3 + c) * p.T + t) * p.fsize + (py * p.patch + ky)) * p.fsize + px * p.patch + kx;
+        const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
+        pe[ti][0] = lo.x; pe[ti][1] = lo.y; pe[ti][2] = lo.z; pe[ti][3] = lo.w;
+        pe[ti][4] = hi.x; pe[ti][5] = hi.y; pe[ti][6] = hi.z; pe[ti][7] = hi.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int kq = k + q;
+          float v = 0.f;
+          if (kq < Kreal) {
+            const int c = kq / P2, rem = kq - c * P2, ky = rem / p.patch, kx = rem - ky * p.patch;
+            v = p.frames[((((long)b * 3 + c) * p.T + t) * p.fsize + (py * p.patch + ky)) * p.fsize + px * p.patch + kx];
+          }
+          pe[ti][q] = v;
+        }
+      }
+    }
+  };
+  auto patch_write = [&](int kt) {
+    char* base = smem + (kt % NST) * STAGE;
+#pragma unroll
+    for (int ti = 0; ti < NTASK; ++ti) {
+      const int task = tid + ti * NW * 64;
+      const int row = task >> 3, chunk = task & 7;
+      const uint2 x = pack4<P>(pe[ti][0], pe[ti][1], pe[ti][2], pe[ti][3]), y = pack4<P>(pe[ti][4], pe[ti][5], pe[ti][6], pe[ti][7]);
+      *reinterpret_cast<uint4*>(base + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = make_uint4(x.x, x.y, y.x, y.y);
+    }
   };
 
   // per-lane fragment read offsets (bytes) inside a stage
@@ -108,7 +161,7 @@ void gemm_kernel(const GemmParams p) {
   const int nk = p.K / BK;
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
-    if (t < nk) stage(t);
+    if (t < nk) { stage(t); if (direct) { patch_load(t); patch_write(t); } }
 
   // Accumulators start at the residual tile (out = resid + A W^T accumulates in fp32 on top of it): the
   // residual read is in flight while the first operand stage lands, instead of being a serialised
@@ -136,8 +189,13 @@ void gemm_kernel(const GemmParams p) {
     if (NST == 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
     else if (NST >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (direct) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's A-tile ds_writes are done
     __builtin_amdgcn_s_barrier();
-    if (kt + NST - 1 < nk && !(p.ablate & 1)) stage(kt + NST - 1);   // refills the slot every wave finished reading at kt-1
+    const bool refill = kt + NST - 1 < nk && !(p.ablate & 1);   // refills the slot every wave finished reading at kt-1
+    if (refill) {
+      stage(kt + NST - 1);
+      if (direct) patch_load(kt + NST - 1);
+    }
     const char* cur = smem + (kt % NST) * STAGE;
     if (p.ablate & 2) continue;
     s16x8_t af[2][4], wf[2][4];
@@ -160,6 +218,7 @@ void gemm_kernel(const GemmParams p) {
     // first half's MFMAs (the compiler emits counted lgkmcnt waits in issue order)
     __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+    if (direct && refill) patch_write(kt + NST - 1);
   }
 
   if (p.ablate & 4) return;
@@ -843,8 +902,9 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
 template <class P>
 int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   static const int variant = getenv("GAVA_GEMM_VARIANT") ? atoi(getenv("GAVA_GEMM_VARIANT")) : 0;
-  // small-M problems (prompt path, text tower at few classes): 128x128 tiles fill more CUs
-  if (gp.M <= 2048 || variant == 1) return launch_tile<P, 128, 128, 2>(gp, epi, s);
+  // small-M problems (prompt path, text tower at few classes): 128x128 tiles fill more CUs;
+  // the im2col-free patch loader lives in the templated kernel
+  if (gp.frames || gp.M <= 2048 || variant == 1) return launch_tile<P, 128, 128, 2>(gp, epi, s);
   if (variant == 2) return launch_tile<P, 256, 128, 3>(gp, epi, s);
   // measured at M = 100864 (c2): the persistent 256^2 kernel wins for N >= 1536 (qkv 0.48 vs 0.58 ms,
   // fc1 0.67 vs 0.78 ms); at N = 768 its 1182 tiles quantise badly over 256 workgroups (fc2 0.73 vs 0.68)
@@ -857,11 +917,18 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
 }  // namespace
 
 extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
-  if (!a || !a->A || !a->W || !a->out) return GAVA_EINVAL;
+  const bool patch_direct = a && a->epilogue == GAVA_EPI_F32_PATCH && !a->A && a->frames;
+  if (!a || (!a->A && !patch_direct) || !a->W || !a->out) return GAVA_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return GAVA_EINVAL;
   if (a->N % 128 || a->K % BK) return GAVA_EINVAL;
-  if (a->lda % 8 || a->ldw % 8 || a->lda < a->K || a->ldw < a->K) return GAVA_EINVAL;
-  if (((uintptr_t)a->A | (uintptr_t)a->W | (uintptr_t)a->out) & 15) return GAVA_EINVAL;
+  if (a->ldw % 8 || a->ldw < a->K) return GAVA_EINVAL;
+  if (!patch_direct && (a->lda % 8 || a->lda < a->K)) return GAVA_EINVAL;
+  if (patch_direct && (a->patch <= 0 || a->frame_size % a->patch || 3 * a->patch * a->patch > a->K ||
+                       (a->frame_size / a->patch) * (a->frame_size / a->patch) != a->n_patches || ((uintptr_t)a->frames & 15) ||
+                       ((a->patch & 7) == 0 && (a->frame_size & 3))))
+    return GAVA_EINVAL;
+  if (((uintptr_t)a->W | (uintptr_t)a->out) & 15) return GAVA_EINVAL;
+  if (a->A && ((uintptr_t)a->A & 15)) return GAVA_EINVAL;
   if (a->bias && ((uintptr_t)a->bias & 15)) return GAVA_EINVAL;
   if (a->ldo % 4 || a->ldo < (a->split_out ? 3 : 1) * (int64_t)a->N) return GAVA_EINVAL;
   if (a->split_out && a->epilogue != GAVA_EPI_H16 && a->epilogue != GAVA_EPI_H16_QGELU) return GAVA_EINVAL;
@@ -876,6 +943,7 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.M = a->M; gp.N = a->N; gp.K = a->K;
   gp.scale_cols = a->scale_cols; gp.scale = a->scale;
   gp.pos = a->pos; gp.time = a->time; gp.n_patches = a->n_patches; gp.T = a->T;
+  gp.frames = patch_direct ? a->frames : nullptr; gp.fsize = a->frame_size; gp.patch = a->patch;
   gp.split_out = a->split_out;
   static const int ablate = getenv("GAVA_GEMM_ABLATE") ? atoi(getenv("GAVA_GEMM_ABLATE")) : 0;
   gp.ablate = ablate;

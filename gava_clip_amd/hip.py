@@ -28,7 +28,8 @@ class GemmArgs(C.Structure):
                 ("out", _vp), ("ldo", C.c_int64), ("resid", _fp), ("ldr", C.c_int64),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int), ("prec", C.c_int),
                 ("scale_cols", C.c_int), ("scale", C.c_float),
-                ("pos", _fp), ("time", _fp), ("n_patches", C.c_int), ("T", C.c_int), ("split_out", C.c_int)]
+                ("pos", _fp), ("time", _fp), ("n_patches", C.c_int), ("T", C.c_int),
+                ("frames", _fp), ("frame_size", C.c_int), ("patch", C.c_int), ("split_out", C.c_int)]
 
 
 class LayerNormArgs(C.Structure):
@@ -142,9 +143,10 @@ def h16_dtype(prec):
 # ---- thin per-op wrappers (used by the unit tests; the model uses the fused drivers) ----------
 
 def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0,
-         pos=None, time=None, n_patches=0, T=0, M=None, split_out=False):
+         pos=None, time=None, n_patches=0, T=0, M=None, split_out=False, frames=None, frame_size=0, patch=0):
     a = GemmArgs()
-    a.A, a.lda, a.W, a.ldw = ptr(A), A.stride(0), ptr(W), W.stride(0)
+    a.A, a.lda, a.W, a.ldw = ptr(A), (A.stride(0) if A is not None else W.stride(0)), ptr(W), W.stride(0)
+    a.frames, a.frame_size, a.patch = ptr(frames), frame_size, patch
     a.bias, a.out, a.ldo = ptr(bias), ptr(out), out.stride(0)
     a.resid, a.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
     a.M, a.N, a.K = (A.shape[0] if M is None else M), W.shape[0], W.shape[1]

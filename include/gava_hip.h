@@ -65,6 +65,11 @@ typedef struct {
    * frame*(n_patches+1) + 1 + p with + pos[(1+p)][:] + time[(frame % T)][:]
    * (VitaCLIP_vision_encoder.py:108-111,86-100). */
   const float* pos; const float* time; int n_patches; int T;
+  /* EPI_F32_PATCH with A == NULL: im2col-free patch embedding.  The A tile is built on the fly from the
+   * frames `frames` = fp32 (B,3,T,size,size): row m = frame*n_patches + p, column k = (c,ky,kx) reads
+   * frames[b][c][t][py*P+ky][px*P+kx] (frame = b*T+t); loaded coalesced, converted to h16 and written to
+   * the swizzled LDS tile, never materialised in HBM.  K = 3*P*P rounded up to 64 (W zero-padded). */
+  const float* frames; int frame_size; int patch;
   /* EPI_H16 / EPI_H16_QGELU: split-precision output.  Row layout becomes [hi(N) | lo(N) | hi(N)]
    * (ldo >= 3N) with lo = h16(v - hi): the A operand of a following GEMM whose weight is packed
    * [W_hi | W_hi | W_lo] (K' = 3K), i.e. A_hi W_hi + A_lo W_hi + A_hi W_lo in one pass. */

@@ -236,3 +236,30 @@ def test_gemm_large_m_patch_split_and_ragged(prec):
     assert torch.equal(out[:M, :D], out[:M, 2 * D:])
     assert torch.all(out[M:] == 3.0)
     assert torch.allclose(hi + lo, r, rtol=3e-5 if prec == hip.PREC_F16 else 3e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("size,patch,B,T", [(64, 16, 2, 3), (56, 14, 1, 2), (224, 16, 1, 2)])
+def test_gemm_patch_embed_im2col_free(prec, size, patch, B, T):
+    """EPI_F32_PATCH with A == NULL: the A tile is built from the NCTHW fp32 frames inside the kernel."""
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    g = size // patch
+    n, D = g * g, 128
+    K = 3 * patch * patch
+    Kp = (K + 63) // 64 * 64
+    x = rnd((B, 3, T, size, size), 1.0, 51).to(d)
+    Wf = rnd((D, K), K ** -0.5, 52)
+    W = torch.zeros(D, Kp); W[:, :K] = Wf
+    W = W.to(d).to(dt)
+    bias, pos, tim = rnd((D,), 1, 53).to(d), rnd((n + 1, D), 1, 54).to(d), rnd((T, D), 1, 55).to(d)
+    X = torch.zeros(B * T * (n + 1), D, device=d)
+    hip.gemm(None, W, bias, X, epilogue=hip.EPI_F32_PATCH, prec=prec, pos=pos, time=tim, n_patches=n, T=T,
+             M=B * T * n, frames=x, frame_size=size, patch=patch)
+    frames = x.permute(0, 2, 1, 3, 4).reshape(B * T, 3, size, size)
+    cols = frames.view(B * T, 3, g, patch, g, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * T, n, K)
+    ref = cols.to(dt).float() @ W[:, :K].float().t() + bias + pos[1:].unsqueeze(0) \
+        + tim[torch.arange(B * T, device=d) % T].unsqueeze(1)
+    Xv = X.view(B * T, n + 1, D)
+    assert torch.allclose(Xv[:, 1:], ref, rtol=1e-4, atol=1e-4)
+    assert torch.all(Xv[:, 0] == 0)

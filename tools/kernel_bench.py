@@ -39,6 +39,14 @@ elif a.which == "qkv":
 elif a.which == "out":
     A, W, b, O = rn(R, D), rn(D, D, scale=D ** -0.5), rn(D, dtype=torch.float32), rn(R, D, dtype=torch.float32)
     fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32, prec=prec, resid=O); fl = 2.0 * R * D * D
+elif a.which == "patch":
+    n, Kp = 196, 768
+    x = torch.randn(a.B, 3, T, 224, 224, device=d, generator=g)
+    W, b, pos, tim = rn(D, Kp, scale=Kp ** -0.5), rn(D, dtype=torch.float32), rn(n + 1, D, dtype=torch.float32), rn(T, D, dtype=torch.float32)
+    O = torch.zeros(BT * (n + 1), D, device=d)
+    fn = lambda: hip.gemm(None, W, b, O, epilogue=hip.EPI_F32_PATCH, prec=prec, pos=pos, time=tim, n_patches=n, T=T,
+                          M=BT * n, frames=x, frame_size=224, patch=16)
+    fl = 2.0 * BT * n * D * Kp
 elif a.which == "attn":
     QKV, side, O = rn(R, 3 * D), rn(G + 2 * BT, 2 * D), torch.empty(R, D, dtype=dt, device=d)
     fn = lambda: hip.attention(QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, batch=BT, heads=H, n_q=n1, n_kmain=n1,
