@@ -235,22 +235,29 @@ __global__ void l2norm_rows_kernel(const float* in, float* out, int rows, int E)
   for (int c = lane; c < E; c += 64) out[(long)row * E + c] = in[(long)row * E + c] * inv;
 }
 
-__global__ void logits_kernel(const float* vn, const float* tn, const float* logit_scale, const float* logit_bias,
-                              int B, int C, int n_kv, int E, float* logits) {
-  const int lane = threadIdx.x & 63;
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (o >= B * C) return;
-  const int b = o / C, c = o % C;
+// logits = exp(logit_scale) * V T^T (+ bias) as ONE fp32 MFMA GEMM: v_mfma_f32_16x16x4_f32 is bit-for-bit an
+// fp32 fma chain (exact f32, no reduced-precision path), which the similarity head needs.  One wave per
+// 16x16 output tile; lane l feeds A[i=l&15][k=l>>4] = V[b0+i][k0+k] and B[k=l>>4][j=l&15] = T[c0+j][k0+k];
+// D: column = lane&15 (class), row = 4*(lane>>4)+r (clip).
+__global__ __launch_bounds__(64) void logits_mfma_kernel(const float* vn, const float* tn, const float* logit_scale,
+                                                         const float* logit_bias, int B, int C, int E, float* logits) {
+  const int lane = threadIdx.x;
+  const int tiles_c = (C + 15) / 16;
+  const int b0 = (blockIdx.x / tiles_c) * 16, c0 = (blockIdx.x % tiles_c) * 16;
+  const int i = lane & 15, kq = lane >> 4;
+  const int vb = b0 + i < B ? b0 + i : B - 1, tc = c0 + i < C ? c0 + i : C - 1;
+  const float* vp = vn + (long)vb * E + kq;
+  const float* tp = tn + (long)tc * E + kq;
+  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < E; k0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[k0], tp[k0], acc, 0, 0, 0);
   const float ls = expf(logit_scale[0]);
-  float acc = 0.f;
-  for (int k = 0; k < n_kv; ++k) {
-    float s = 0.f;
-    for (int e = lane; e < E; e += 64) s += vn[(long)b * E + e] * tn[((long)c * n_kv + k) * E + e];
-    acc += ls * wave_sum(s);
+  const float lb = logit_bias ? logit_bias[0] : 0.f;
+  const int c = c0 + i;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * kq + r;
+    if (b < B && c < C) logits[(long)b * C + c] = ls * acc[r] + lb;
   }
-  acc /= (float)n_kv;
-  if (logit_bias) acc += logit_bias[0];
-  if (lane == 0) logits[o] = acc;
 }
 
 // text_features[c] = normalise(mean_k tn[c][k])
@@ -317,8 +324,9 @@ extern "C" int gava_similarity_head(const float* video, const float* text, const
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(l2norm_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, s, video, video_norm, B, E);
   hipLaunchKernelGGL(l2norm_rows_kernel, dim3((C + 3) / 4), dim3(256), 0, s, text, text_features, C, E);
-  hipLaunchKernelGGL(logits_kernel, dim3((B * C + 3) / 4), dim3(256), 0, s, video_norm, text_features, logit_scale,
-                     logit_bias, B, C, 1, E, logits);
+  if (E % 4) return GAVA_EINVAL;
+  hipLaunchKernelGGL(logits_mfma_kernel, dim3(((B + 15) / 16) * ((C + 15) / 16)), dim3(64), 0, s, video_norm,
+                     text_features, logit_scale, logit_bias, B, C, E, logits);
   // second normalisation of the per-class mean (VitaCLIP_model.py:290-291); with n_kv == 1 the
   // mean is the row itself, so this re-normalises an already unit row exactly as upstream does.
   hipLaunchKernelGGL(text_feature_kernel, dim3((C + 3) / 4), dim3(256), 0, s, text_features, text_features, C, 1, E);
