@@ -2,8 +2,33 @@
 // Pure launch code: no allocation, no synchronisation, capturable into a hipGraph.
 #include "common.h"
 #include "internal.h"
+#include <stdlib.h>
 
 namespace {
+
+// Second stream for the prompt ("side") path of every block.  Created once on first use (the only
+// allocation the library ever makes); fork/join by events, so a capturing caller records a proper
+// fork-join graph.  GAVA_SIDE_STREAM=0 keeps everything on the caller's stream.
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork[64], join[64];
+  bool ok = false, tried = false;
+  bool get() {
+    if (tried) return ok;
+    tried = true;
+    const char* e = getenv("GAVA_SIDE_STREAM");
+    if (e && e[0] == '0') return false;
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return false;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) return false;
+    for (int i = 0; i < 64; ++i)
+      if (hipEventCreateWithFlags(&fork[i], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return false;
+    ok = true;
+    return true;
+  }
+};
+SideStream g_side;
 
 struct Carver {
   char* base; size_t off, cap;
@@ -107,6 +132,7 @@ extern "C" int gava_vision_forward(const gava_vision_model* m, const float* x, f
   const VisionWs w = carve_vision(m, workspace, workspace_bytes);
   if (w.total > workspace_bytes) return GAVA_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  gava::set_gemm_cu_reserve(0);
   const int g = m->size / m->P, n = g * g, BT = m->B * m->T_in, R = BT * (n + 1);
   const int D = m->D, F = m->F, E = m->E, G = m->G, Tm = m->T_model, pr = m->prec;
   const int Kp = patch_k(m), SR = G + 2 * BT;
@@ -130,26 +156,37 @@ extern "C" int gava_vision_forward(const gava_vision_model* m, const float* x, f
   for (int i = 0; i < m->layers; ++i) {
     const gava_vision_layer& L = m->layer[i];
     const unsigned short* wqkv = (const unsigned short*)L.w_qkv;
-    // prompt ("side") path: cls_proj, summary token, local prompts -> K/V-only rows
-    TRY(ln(w.X, fs, nullptr, nullptr, nullptr, w.CLS16, D, nullptr, 0, BT, D, pr, stream));
-    TRY(gemm(w.CLS16, D, L.w_cls, D, L.b_cls, w.CP, D, BT, D, D, GAVA_EPI_F32, pr, stream));
-    TRY(ln(w.CP, D, nullptr, L.sln_g, L.sln_b, w.CPn, D, nullptr, 0, BT, D, pr, stream));
-    TRY(gemm(w.CPn, D, L.w_sqkv, D, L.b_sqkv, w.SQKV, 3 * D, BT, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+    // prompt ("side") path: cls_proj, summary token, local prompts -> K/V-only rows.  The main path does not
+    // need it before attention, so it runs on the side stream next to LN1 + the QKV GEMM.
+    const bool two = g_side.get() && m->layers <= 64;
+    gava_stream_t ss = two ? (gava_stream_t)g_side.s : stream;
+    if (two) {
+      if (hipEventRecord(g_side.fork[i], s) != hipSuccess || hipStreamWaitEvent(g_side.s, g_side.fork[i], 0) != hipSuccess)
+        return GAVA_ELAUNCH;
+    }
+    TRY(ln(w.X, fs, nullptr, nullptr, nullptr, w.CLS16, D, nullptr, 0, BT, D, pr, ss));
+    TRY(gemm(w.CLS16, D, L.w_cls, D, L.b_cls, w.CP, D, BT, D, D, GAVA_EPI_F32, pr, ss));
+    TRY(ln(w.CP, D, nullptr, L.sln_g, L.sln_b, w.CPn, D, nullptr, 0, BT, D, pr, ss));
+    TRY(gemm(w.CPn, D, L.w_sqkv, D, L.b_sqkv, w.SQKV, 3 * D, BT, 3 * D, D, GAVA_EPI_H16, pr, ss, nullptr, 0, D, 0.125f));
     {
       gava_attention_args a{};
       const unsigned short* q = (const unsigned short*)w.SQKV;
       a.q = q; a.k = q + D; a.v = q + 2 * D; a.ld_qkv = 3 * D; a.out = w.SMIX; a.ld_out = D;
       a.batch = BT / Tm; a.heads = m->H; a.n_q = Tm; a.n_kmain = Tm; a.prec = pr;
-      TRY(gava_attention(&a, stream));
+      TRY(gava_attention(&a, ss));
     }
-    TRY(gemm(w.SMIX, D, L.w_sout, D, L.b_sout, w.SUMM, D, BT, D, D, GAVA_EPI_F32, pr, stream, w.CP, D));
-    TRY(gava::side_ln(L.global_prompts, L.local_prompts, w.CP, w.SUMM, L.ln1_g, L.ln1_b, w.SIDEn, G, Tm, BT, D, pr, s));
-    TRY(gemm(w.SIDEn, D, wqkv + (long)D * D, D, L.b_qkv + D, w.SIDEKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, stream));
+    TRY(gemm(w.SMIX, D, L.w_sout, D, L.b_sout, w.SUMM, D, BT, D, D, GAVA_EPI_F32, pr, ss, w.CP, D));
+    TRY(gava::side_ln(L.global_prompts, L.local_prompts, w.CP, w.SUMM, L.ln1_g, L.ln1_b, w.SIDEn, G, Tm, BT, D, pr, (hipStream_t)ss));
+    TRY(gemm(w.SIDEn, D, wqkv + (long)D * D, D, L.b_qkv + D, w.SIDEKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, ss));
+    if (two && hipEventRecord(g_side.join[i], g_side.s) != hipSuccess) return GAVA_ELAUNCH;
+    gava::set_gemm_cu_reserve(two ? 8 : 0);   // the persistent QKV GEMM leaves 8 CUs to the side kernels
     // main path
     TRY(ln(w.X, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
     const unsigned short* sk = (const unsigned short*)w.SIDEKV;
     if (i + 1 < m->layers) {
       TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+      gava::set_gemm_cu_reserve(0);
+      if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
       {
         gava_attention_args a{};
         const unsigned short* q = (const unsigned short*)w.QKV;
@@ -171,6 +208,8 @@ extern "C" int gava_vision_forward(const gava_vision_model* m, const float* x, f
       // 1/197 of the row work.
       TRY(gemm(w.Xn, D, wqkv + (long)D * D, D, L.b_qkv + D, (unsigned short*)w.QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream));
       TRY(gemm(w.Xn, fs, L.w_qkv, D, L.b_qkv, w.QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+      gava::set_gemm_cu_reserve(0);
+      if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
       {
         gava_attention_args a{};
         const unsigned short* q = (const unsigned short*)w.QKV;

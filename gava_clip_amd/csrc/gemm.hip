@@ -328,6 +328,7 @@ void gemm256_kernel(const GemmParams p) {
   constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;   // 32 KiB, 64 KiB
   constexpr int PPW = (BM + BN) / 8 / NW;                            // 8 glds per wave per stage
   constexpr int NSTORE = (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH) ? 32 : (SPLIT ? 48 : 16);
+  constexpr bool ACC_RES = EPI == GAVA_EPI_F32 && RES;   // accumulators start at the residual tile
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -392,21 +393,26 @@ void gemm256_kernel(const GemmParams p) {
   const int w_k0 = (fg ^ swb) << 4, w_k1 = ((4 + fg) ^ swb) << 4;
 
   f32x4_t acc[8][4];
+  // residual tile (rows mm0+wr*128+i*16+fr, columns nn0+wc*64+16*fg+4*jj..) straight into accumulator i
+  auto load_resid = [&](int i, int mm0, int nn0) {
+    int m = mm0 + wr * 128 + i * 16 + fr;
+    m = m < p.M ? m : p.M - 1;
+    const float* rp = p.resid + (long)m * p.ldr + nn0 + wc * 64 + 16 * fg;
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = *reinterpret_cast<const f32x4_t*>(rp + 4 * jj);
+  };
 
-  // De-phase the workgroups of an XCD (GAVA_GEMM_ABLATE bit 16, experiment): persistent workgroups with
-  // equal tiles run in lockstep, so all 32 of an XCD store their tiles (32 x 128 KiB = the whole 4 MiB
-  // L2) at the same moment and the stores drain at HBM speed while every wave waits on the in-order
-  // vmcnt.  Spread over one tile time, each burst fits in L2.
-  if (p.ablate & 16) {
-    const long delay = (long)slot * nk * 2500 / per_xcd;     // cycles; one tile ~ nk * 2500
-    for (long d = 0; d < delay; d += 8128) __builtin_amdgcn_s_sleep(127);
-  }
   int m0, n0, m0n, n0n;
   tile_coords(0, m0, n0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (ACC_RES) {
+      load_resid(i, m0, n0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+  }
   set_src(m0, n0);
   stage(0, 0);
   bool counted = false;   // the next wait may leave this wave's NSTORE epilogue stores in flight
@@ -532,16 +538,6 @@ void gemm256_kernel(const GemmParams p) {
           }
         } else {
           float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + nb0;
-          if (EPI == GAVA_EPI_F32 && RES) {
-            const float* rp = p.resid + orow * p.ldr + nb0;
-            float4 rr[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) rr[jj] = *reinterpret_cast<const float4*>(rp + 4 * jj);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              v[4 * jj] += rr[jj].x; v[4 * jj + 1] += rr[jj].y; v[4 * jj + 2] += rr[jj].z; v[4 * jj + 3] += rr[jj].w;
-            }
-          }
           if (EPI == GAVA_EPI_F32_PATCH) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -555,12 +551,19 @@ void gemm256_kernel(const GemmParams p) {
             *reinterpret_cast<float4*>(o + 4 * jj) = make_float4(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
         }
       }
+      // next tile: its residual rows go straight into the accumulators just freed (all 32 loads in flight
+      // together, no temporaries, no wait inside the epilogue)
+      if (ACC_RES && j + 1 < my_tiles) {
+        load_resid(i, m0n, n0n);
+      } else {
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      }
     }
-    // a full tile issued exactly NSTORE stores per wave after the in-flight stage: they may stay in
-    // flight over the next wait.  (Ragged tiles store fewer: fall back to vmcnt(0).)
-    counted = full && !(p.ablate & 4);
+    // a full tile issued exactly NSTORE stores per wave after the in-flight stage: they may stay in flight
+    // over the next wait (ragged tiles store fewer, and the accumulator-residual loads add to the count:
+    // those cases fall back to vmcnt(0)).
+    counted = full && !ACC_RES && !(p.ablate & 4);
     m0 = m0n; n0 = n0n;
   }
 }
@@ -873,7 +876,8 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
     n_cu = prop.multiProcessorCount / 8 * 8;
     if (n_cu <= 0) n_cu = 8;
   }
-  const int blocks = gp.n_tiles < n_cu ? (gp.n_tiles + 7) / 8 * 8 : n_cu;
+  const int avail = n_cu - gava::gemm_cu_reserve() > 8 ? (n_cu - gava::gemm_cu_reserve()) / 8 * 8 : 8;
+  const int blocks = gp.n_tiles < avail ? (gp.n_tiles + 7) / 8 * 8 : avail;
   dim3 grid(blocks), block(512);
 #define GAVA_LAUNCH(EPI, RES, SPLIT)                                                               \
   do {                                                                                             \

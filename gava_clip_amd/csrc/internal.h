@@ -11,5 +11,8 @@ int mean_rows(const float* in, float* out, int B, int T, int D, hipStream_t s);
 int copy_rows(const float* in, long in_stride, float* out, int rows, int D, hipStream_t s);
 int text_embed(const float* emb, const float* pos, const float* ctx, const int* tok, float* X,
                int n_prompts, int L, int W, int n_ctx, hipStream_t s);
-unsigned long long* debug_buffer();   // set by gava_debug_set_buffer; nullptr = stamps off
+unsigned long long* debug_buffer();
+// CUs the persistent GEMM leaves free on its next launches (so a concurrent stream can run small kernels)
+void set_gemm_cu_reserve(int n);
+int gemm_cu_reserve();   // set by gava_debug_set_buffer; nullptr = stamps off
 }  // namespace gava

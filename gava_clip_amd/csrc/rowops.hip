@@ -339,8 +339,11 @@ extern "C" int gava_debug_set_buffer(void* dev_u64) {
   g_debug_buffer = (unsigned long long*)dev_u64;
   return GAVA_OK;
 }
+static int g_cu_reserve = 0;
 namespace gava {
 unsigned long long* debug_buffer() { return g_debug_buffer; }
+void set_gemm_cu_reserve(int n) { g_cu_reserve = n; }
+int gemm_cu_reserve() { return g_cu_reserve; }
 }
 
 // ---- internal launchers used by the fused drivers -------------------------------------------
