@@ -243,7 +243,7 @@ def main():
         tpath = os.path.join(REPO, "profiles", "traffic.json")   # HBM bytes/launch from the committed PMC passes
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("gemm_fc1_bytes_per_launch")
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<.., EPI_H16_QGELU> (vision fc1, M=%d N=%d K=%d)" % (
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm256_kernel<PrecF16|PrecBF16, EPI_H16_QGELU> (vision fc1, M=%d N=%d K=%d)" % (
                                B * cfg.num_frames * cfg.tokens_main, cfg.mlp_dim, cfg.feature_dim),
                            "achieved": fc1["tflops"], "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(fc1["tflops"] / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
