@@ -570,6 +570,293 @@ void gemm256_kernel(const GemmParams p) {
 
 
 // ---------------------------------------------------------------------------------------------
+// v7 "rotated-k": v3 whose two wave groups (waves 0-3 / 4-7, the SIMD partners) are E operand stages out
+// of phase, so that each group's epilogue - VALU, conversions and the store issue tail - runs while its
+// partner feeds the matrix pipe.
+//   * The operand stream of a tile has CYC = nk + E stages: k-slices 0..nk-1, then slices 0..E-1 again.
+//     Every wave is at the same stream position (one barrier per stage, as in v3), every wave issues its
+//     share of each stage's LDS-DMA.
+//   * Both groups run ONE program - [epilogue of the previous tile in E chunks] [nk compute stages] - and
+//     group 1 simply skips the first (empty) epilogue phase.  Group 1 therefore computes a tile on stream
+//     stages 0..nk-1 and stores it on nk..CYC-1; group 0 stores the previous tile on stages 0..E-1 and
+//     computes on E..CYC-1, i.e. slices E..nk-1, 0..E-1: the same sum in a rotated order.
+//   * An MFMA never cares which k-slice it gets, only which LDS slot: slot = stream position & 1.
+// Cost: E/nk more L2->LDS traffic.  Gain: the epilogue leaves the critical path of the matrix pipe.
+template <class P, int EPI, bool RES, bool SPLIT, int E>
+__global__ __launch_bounds__(512, 2)
+void gemm256r_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, NW = 8;
+  constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;   // 32 KiB, 64 KiB
+  constexpr int PPW = (BM + BN) / 8 / NW;                            // 8 glds per wave per stage
+  constexpr int RPC = 8 / E;                                         // accumulator rows per epilogue chunk
+  constexpr int ROW_STORES = (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH) ? 4 : (SPLIT ? 6 : 2);
+  constexpr int CH_STORES = RPC * ROW_STORES;
+  constexpr bool ACC_RES = EPI == GAVA_EPI_F32 && RES;   // accumulators start at the residual tile
+  static_assert(E == 2 || E == 4 || E == 8, "chunks must tile the 8 accumulator rows");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  const int nwg = p.n_tiles, nb = gridDim.x;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = nb >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int x_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int x_count = xcd < r ? q + 1 : q;
+  const int my_tiles = slot < x_count ? (x_count - slot + per_xcd - 1) / per_xcd : 0;
+  if (my_tiles == 0) return;
+  const int nk = p.K / BK;
+  const int CYC = nk + E;
+  const int S = my_tiles * CYC;   // stream length in stages
+
+  auto tile_coords = [&](int j, int& m0, int& n0) {
+    const int wg = x_first + slot + j * per_xcd;
+    const int per_group = p.sm * p.tiles_n;
+    const int g = wg / per_group, first_m = g * p.sm;
+    const int sm = min(p.sm, p.tiles_m - first_m);
+    const int w = wg - g * per_group;
+    const int chunk = w / (sm * p.sn), rr = w - chunk * (sm * p.sn);
+    m0 = (first_m + rr % sm) * BM;
+    n0 = (chunk * p.sn + rr / sm) * BN;
+  };
+
+  unsigned src[PPW];
+  auto set_src = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int piece = wave + i * NW;
+      const int row = (piece & 31) * 8 + (lane >> 3);
+      if (i < PPW / 2) {
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        src[i] = (unsigned)gm * (unsigned)p.lda + chunk * 8;
+      } else {
+        const int chunk = (lane & 7) ^ (((row >> 1) & 1) | (((row >> 4) & 3) << 1));
+        src[i] = (unsigned)(n0 + row) * (unsigned)p.ldw + chunk * 8;
+      }
+    }
+  };
+  auto stage = [&](int sl, int kt) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR((i < PPW / 2 ? p.A : p.W) + (size_t)(src[i] + (unsigned)(kt * BK))),
+                                       LDS_PTR(void, smem + sl * STAGE + (wave + i * NW) * 1024), 16, 0, 0);
+  };
+
+  // the stream cursor: next stage to be fetched (tile dj, in-cycle index dr, position dpos)
+  int dj = 0, dr = 0, dpos = 0, dm0, dn0;
+  auto dma_next = [&]() {
+    if (dj < my_tiles) {
+      stage(dpos & 1, dr < nk ? dr : dr - nk);
+      ++dpos;
+      if (++dr == CYC) {
+        dr = 0;
+        if (++dj < my_tiles) {
+          tile_coords(dj, dm0, dn0);
+          set_src(dm0, dn0);
+        }
+      }
+    }
+  };
+
+  const int swa = fr >> 1;
+  const int swb = ((fr >> 1) & 1) | ((fr >> 2) << 1);
+  const int a_off = (wr * 128 + fr) * 128;
+  const int w_off = A_BYTES + (wc * 64 + 16 * (fr >> 2) + (fr & 3)) * 128;
+  const int a_k0 = (fg ^ swa) << 4, a_k1 = ((4 + fg) ^ swa) << 4;
+  const int w_k0 = (fg ^ swb) << 4, w_k1 = ((4 + fg) ^ swb) << 4;
+
+  f32x4_t acc[8][4];
+  auto load_resid = [&](int i, int mm0, int nn0) {
+    int m = mm0 + wr * 128 + i * 16 + fr;
+    m = m < p.M ? m : p.M - 1;
+    const float* rp = p.resid + (long)m * p.ldr + nn0 + wc * 64 + 16 * fg;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = *reinterpret_cast<const f32x4_t*>(rp + 4 * jj);
+  };
+
+  int m0p = 0, n0p = 0, m0c, n0c;
+  tile_coords(0, m0c, n0c);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (ACC_RES) {
+      load_resid(i, m0c, n0c);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  tile_coords(0, dm0, dn0);
+  set_src(dm0, dn0);
+  dma_next();   // stream position 0
+
+  int pos = 0;
+  bool counted = false;   // the next wait may leave this wave's CH_STORES chunk stores in flight
+  auto sync = [&]() {
+    if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH_STORES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    counted = false;
+    __builtin_amdgcn_s_barrier();
+  };
+
+  bool skip = wr == 1;   // group 1 starts in its compute phase
+  for (int c = 0; c <= my_tiles; ++c) {
+    if (c > 0 && c < my_tiles) tile_coords(c, m0c, n0c);
+    if (!skip) {
+      // ---- epilogue of tile c-1 in E chunks, one stream stage each; lane holds out[m][n .. n+15],
+      //      m = m0p + wr*128 + i*16 + fr, n = n0p + wc*64 + 16*fg + 4*jj + r
+      const int nb0 = n0p + wc * 64 + 16 * fg;
+      float4 bj[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        bj[jj] = (p.bias && c > 0) ? *reinterpret_cast<const float4*>(p.bias + nb0 + 4 * jj) : make_float4(0, 0, 0, 0);
+      const bool full = m0p + BM <= p.M;
+      auto chunk = [&](auto CH) __attribute__((always_inline)) {
+        constexpr int ch = decltype(CH)::value;
+        if (pos < S) {
+          sync();
+          dma_next();
+        }
+        ++pos;
+        if (c == 0) return;
+#pragma unroll
+        for (int ii = 0; ii < RPC; ++ii) {
+          const int i = ch * RPC + ii;
+          const int m = m0p + wr * 128 + i * 16 + fr;
+          if (m < p.M && !(p.ablate & 4)) {
+            long orow = m;
+            const float* posr = nullptr;
+            const float* timr = nullptr;
+            if (EPI == GAVA_EPI_F32_PATCH) {
+              const int frame = m / p.n_patches, pp = m - frame * p.n_patches;
+              orow = (long)frame * (p.n_patches + 1) + 1 + pp;
+              posr = p.pos + (long)(1 + pp) * p.N + nb0;
+              timr = p.time + (long)(frame % p.T) * p.N + nb0;
+            }
+            float v[16];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              v[4 * jj + 0] = acc[i][jj][0] + bj[jj].x; v[4 * jj + 1] = acc[i][jj][1] + bj[jj].y;
+              v[4 * jj + 2] = acc[i][jj][2] + bj[jj].z; v[4 * jj + 3] = acc[i][jj][3] + bj[jj].w;
+            }
+            if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU) {
+              if (EPI == GAVA_EPI_H16) {
+                if (nb0 < p.scale_cols) {
+#pragma unroll
+                  for (int e = 0; e < 16; ++e) v[e] *= p.scale;
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = quick_gelu(v[e]);
+              }
+              unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + nb0;
+              if (SPLIT) {
+                uint2 hi[4], lo[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) split4<P>(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3], hi[jj], lo[jj]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  const uint4 H = make_uint4(hi[2 * h].x, hi[2 * h].y, hi[2 * h + 1].x, hi[2 * h + 1].y);
+                  const uint4 L = make_uint4(lo[2 * h].x, lo[2 * h].y, lo[2 * h + 1].x, lo[2 * h + 1].y);
+                  *reinterpret_cast<uint4*>(o + 8 * h) = H;
+                  *reinterpret_cast<uint4*>(o + p.N + 8 * h) = L;
+                  *reinterpret_cast<uint4*>(o + 2 * p.N + 8 * h) = H;
+                }
+              } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  const uint2 x = pack4<P>(v[8 * h], v[8 * h + 1], v[8 * h + 2], v[8 * h + 3]);
+                  const uint2 y = pack4<P>(v[8 * h + 4], v[8 * h + 5], v[8 * h + 6], v[8 * h + 7]);
+                  *reinterpret_cast<uint4*>(o + 8 * h) = make_uint4(x.x, x.y, y.x, y.y);
+                }
+              }
+            } else {
+              float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + nb0;
+              if (EPI == GAVA_EPI_F32_PATCH) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                  const float4 pr = *reinterpret_cast<const float4*>(posr + 4 * jj);
+                  const float4 tr = *reinterpret_cast<const float4*>(timr + 4 * jj);
+                  v[4 * jj] += pr.x + tr.x; v[4 * jj + 1] += pr.y + tr.y; v[4 * jj + 2] += pr.z + tr.z; v[4 * jj + 3] += pr.w + tr.w;
+                }
+              }
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj)
+                *reinterpret_cast<float4*>(o + 4 * jj) = make_float4(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
+            }
+          }
+          // this group's next tile: its residual rows go straight into the accumulators just freed
+          if (ACC_RES && c < my_tiles) {
+            load_resid(i, m0c, n0c);
+          } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        // a full tile issued exactly CH_STORES stores after this stage's LDS-DMA: they may stay in flight
+        counted = full && !ACC_RES && !(p.ablate & 4);
+      };
+      chunk(std::integral_constant<int, 0>{});
+      chunk(std::integral_constant<int, 1>{});
+      if constexpr (E > 2) { chunk(std::integral_constant<int, 2>{}); chunk(std::integral_constant<int, 3>{}); }
+      if constexpr (E > 4) {
+        chunk(std::integral_constant<int, 4>{}); chunk(std::integral_constant<int, 5>{});
+        chunk(std::integral_constant<int, 6>{}); chunk(std::integral_constant<int, 7>{});
+      }
+    }
+    skip = false;
+    if (c == my_tiles) break;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      sync();
+      if (wave < 4) dma_next();
+      const char* cur = smem + (pos & 1) * STAGE;
+      ++pos;
+      s16x8_t wf0[4], wf1[4], a00[4], a01[4], a10[4], a11[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) wf0[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 512 + w_k0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a00[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 2048 + a_k0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a01[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + (4 + i) * 2048 + a_k0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = P::mfma(wf0[jj], a00[i], acc[i][jj]);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) wf1[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 512 + w_k1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a10[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 2048 + a_k1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[4 + i][jj] = P::mfma(wf0[jj], a01[i], acc[4 + i][jj]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      if (wave >= 4) dma_next();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a11[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + (4 + i) * 2048 + a_k1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = P::mfma(wf1[jj], a10[i], acc[i][jj]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[4 + i][jj] = P::mfma(wf1[jj], a11[i], acc[4 + i][jj]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 32, 1);
+    }
+    m0p = m0c; n0p = n0c;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // v5 "ping-pong" (EXPERIMENTAL, GAVA_GEMM_VARIANT=5): BK = 32 stages in a 4-slot ring (4 x 32 KiB,
 // 64-byte LDS rows, swizzle chunk ^ {0,3,2,1}[g], g = (row>>2)&3 for A and (row>>4)&3 for the
 // row-permuted W tile) with the two wave groups that share
@@ -881,7 +1168,9 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
   dim3 grid(blocks), block(512);
 #define GAVA_LAUNCH(EPI, RES, SPLIT)                                                               \
   do {                                                                                             \
-    if (KERN == 5) hipLaunchKernelGGL((gemm256pp_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp); \
+    if (KERN == 7) hipLaunchKernelGGL((gemm256r_kernel<P, EPI, RES, SPLIT, 2>), grid, block, 0, s, gp); \
+    else if (KERN == 8) hipLaunchKernelGGL((gemm256r_kernel<P, EPI, RES, SPLIT, 4>), grid, block, 0, s, gp); \
+    else if (KERN == 5) hipLaunchKernelGGL((gemm256pp_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp); \
     else hipLaunchKernelGGL((gemm256_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp);         \
   } while (0)
   switch (epi) {
@@ -913,6 +1202,9 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   // measured at M = 100864 (c2): the persistent 256^2 kernel wins for N >= 1536 (qkv 0.48 vs 0.58 ms,
   // fc1 0.67 vs 0.78 ms); at N = 768 its 1182 tiles quantise badly over 256 workgroups (fc2 0.73 vs 0.68)
   if (gp.N % 256 == 0 && gp.K % 384 == 0 && variant == 5) return launch_256<P, 5>(gp, epi, s);
+  const bool fits32r = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
+  if (gp.N % 256 == 0 && gp.K >= 256 && fits32r && variant == 7) return launch_256<P, 7>(gp, epi, s);
+  if (gp.N % 256 == 0 && gp.K >= 256 && fits32r && variant == 8) return launch_256<P, 8>(gp, epi, s);
   const bool fits32 = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
   if (gp.N % 256 == 0 && fits32 && (gp.N >= 1536 || variant == 3)) return launch_256<P, 3>(gp, epi, s);
   return launch_tile<P, 128, 128, 2>(gp, epi, s);
