@@ -20,6 +20,10 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef GAVA_V3_PRIO
+#define GAVA_V3_PRIO 1
+#endif
+
 namespace {
 
 constexpr int BK = 64;
@@ -416,14 +420,26 @@ void gemm256_kernel(const GemmParams p) {
   set_src(m0, n0);
   stage(0, 0);
   bool counted = false;   // the next wait may leave this wave's NSTORE epilogue stores in flight
+  // diagnostic stamps (gava_debug_set_buffer; tools/gemm_stamps.py): cycles in the vmcnt wait, the barrier,
+  // the stage body and the epilogue
+  const bool stamp = p.dbg != nullptr;
+  unsigned long long ts = 0, tW = 0, tB = 0, tC = 0, tE = 0;
+  bool in_epi = false;
+  if (stamp) ts = clock64();
+  // Static priority for the second-dispatched half: at equal priority waves 4-7 lose every issue arbitration to
+  // their older SIMD partners and trail them by ~800 cycles per stage (stamps: stage 4.6k -> 4.1k cycles).
+  if (GAVA_V3_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   for (int j = 0; j < my_tiles; ++j) {
     for (int kt = 0; kt < nk; ++kt) {
       const int g = j * nk + kt;
+      if (stamp) { const unsigned long long t = clock64(); if (in_epi) tE += t - ts; else tC += t - ts; ts = t; in_epi = false; }
       if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       counted = false;
+      if (stamp) { const unsigned long long t = clock64(); tW += t - ts; ts = t; }
       __builtin_amdgcn_s_barrier();
+      if (stamp) { const unsigned long long t = clock64(); tB += t - ts; ts = t; }
       // LDS-DMA issue is expensive (~100+ cycles per 1 KiB piece beside running MFMAs): the two waves
       // that share a SIMD (w and w+4) issue their 8 pieces half an iteration apart, so one of them
       // always feeds the matrix pipe.  Waves 0-3 issue here, waves 4-7 after the second MFMA group.
@@ -478,6 +494,7 @@ void gemm256_kernel(const GemmParams p) {
       __builtin_amdgcn_sched_group_barrier(0x008, 32, 1);  // a10 x wf1, a11 x wf1
     }
 
+    if (stamp) { const unsigned long long t = clock64(); tC += t - ts; ts = t; in_epi = true; }
     // ---- epilogue of tile j: lane holds out[m][n .. n+15], m = m0+wr*128+i*16+fr,
     //      n = n0 + wc*64 + 16*fg + 4*jj + r
     const int nb0 = n0 + wc * 64 + 16 * fg;
@@ -565,6 +582,12 @@ void gemm256_kernel(const GemmParams p) {
     // those cases fall back to vmcnt(0)).
     counted = full && !ACC_RES && !(p.ablate & 4);
     m0 = m0n; n0 = n0n;
+  }
+  if (stamp && lane == 0) {
+    const unsigned long long t = clock64();
+    tE += t - ts;
+    unsigned long long* d = p.dbg + (size_t)(blockIdx.x * 8 + wave) * 8;
+    d[0] = tW; d[1] = tB; d[2] = tC; d[3] = 0; d[4] = tE; d[5] = (unsigned long long)G;
   }
 }
 
@@ -1199,14 +1222,18 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   // the im2col-free patch loader lives in the templated kernel
   if (gp.frames || gp.M <= 2048 || variant == 1) return launch_tile<P, 128, 128, 2>(gp, epi, s);
   if (variant == 2) return launch_tile<P, 256, 128, 3>(gp, epi, s);
-  // measured at M = 100864 (c2): the persistent 256^2 kernel wins for N >= 1536 (qkv 0.48 vs 0.58 ms,
-  // fc1 0.67 vs 0.78 ms); at N = 768 its 1182 tiles quantise badly over 256 workgroups (fc2 0.73 vs 0.68)
+  // measured at M = 100864 (c2): the persistent 256^2 kernel wins for N >= 1536 (qkv 0.42 vs 0.58 ms,
+  // fc1 0.55 vs 0.78 ms) and, since the static wave priority, for the deep-K N = 768 GEMM (fc2 0.59 vs
+  // 0.62 ms); the shallow one (out, K = 768: 0.28 vs 0.26 ms) stays on the 128^2 kernel, whose many small
+  // workgroups spread the fp32 residual traffic better over its short k-loop
   if (gp.N % 256 == 0 && gp.K % 384 == 0 && variant == 5) return launch_256<P, 5>(gp, epi, s);
   const bool fits32r = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
   if (gp.N % 256 == 0 && gp.K >= 256 && fits32r && variant == 7) return launch_256<P, 7>(gp, epi, s);
   if (gp.N % 256 == 0 && gp.K >= 256 && fits32r && variant == 8) return launch_256<P, 8>(gp, epi, s);
   const bool fits32 = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
-  if (gp.N % 256 == 0 && fits32 && (gp.N >= 1536 || variant == 3)) return launch_256<P, 3>(gp, epi, s);
+  const long tiles256 = (long)((gp.M + 255) / 256) * (gp.N / 256);
+  if (gp.N % 256 == 0 && fits32 && (gp.N >= 1536 || (gp.K >= 2048 && tiles256 >= 512) || variant == 3))
+    return launch_256<P, 3>(gp, epi, s);
   return launch_tile<P, 128, 128, 2>(gp, epi, s);
 }
 

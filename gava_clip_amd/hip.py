@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgava_hip.so")
+LIB_PATH = os.environ.get("GAVA_HIP_LIB") or os.path.join(_HERE, "libgava_hip.so")   # env: A/B experiment builds only
 
 PREC_F16, PREC_BF16 = 0, 1
 EPI_H16, EPI_H16_QGELU, EPI_F32, EPI_F32_PATCH = 0, 1, 2, 3

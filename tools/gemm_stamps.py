@@ -3,7 +3,7 @@
 import ctypes as C, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-os.environ["GAVA_GEMM_VARIANT"] = "5"
+os.environ.setdefault("GAVA_GEMM_VARIANT", "5")   # 3: v3 (load = vmcnt wait, wait-b1 = barrier, mfma = stage body)
 import torch
 from gava_clip_amd import hip
 lib = hip.load()
@@ -15,6 +15,9 @@ rn = lambda *s, scale=1.0, dtype=torch.float16: (torch.randn(*s, device="cuda", 
 if which == "fc2":
     A, W, b, O = rn(R, F), rn(D, F, scale=F ** -0.5), rn(D, dtype=torch.float32), rn(R, D, dtype=torch.float32)
     fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32, prec=0, resid=O)
+elif which == "qkv":
+    A, W, b, O = rn(R, D), rn(3 * D, D, scale=D ** -0.5), rn(3 * D, dtype=torch.float32), torch.empty(R, 3 * D, dtype=torch.float16, device="cuda")
+    fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_H16, prec=0, scale_cols=D, scale=0.125)
 else:
     A, W, b, O = rn(R, D), rn(F, D, scale=D ** -0.5), rn(F, dtype=torch.float32), torch.empty(R, F, dtype=torch.float16, device="cuda")
     fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_H16_QGELU, prec=0)
