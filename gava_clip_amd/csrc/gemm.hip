@@ -232,6 +232,10 @@ void gemm_kernel(const GemmParams p) {
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nbase + j * 16) : make_float4(0, 0, 0, 0);
+  // one explicit use on the common path, so that the bias is waited for once and not again (with vmcnt(0),
+  // i.e. for the previous row's stores) in every `m < M` block below
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(bj[j].x), "v"(bj[j].y), "v"(bj[j].z), "v"(bj[j].w));
 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -502,6 +506,10 @@ void gemm256_kernel(const GemmParams p) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
       bj[jj] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb0 + 4 * jj) : make_float4(0, 0, 0, 0);
+    // One explicit use on the common path: the compiler waits for the bias HERE, once.  Without it every row
+    // below (a basic block of its own behind `m < M`) re-waits with vmcnt(0), i.e. for the previous row's stores.
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) asm volatile("" ::"v"(bj[jj].x), "v"(bj[jj].y), "v"(bj[jj].z), "v"(bj[jj].w));
     const bool full = m0 + BM <= p.M;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -735,6 +743,8 @@ void gemm256r_kernel(const GemmParams p) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
         bj[jj] = (p.bias && c > 0) ? *reinterpret_cast<const float4*>(p.bias + nb0 + 4 * jj) : make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) asm volatile("" ::"v"(bj[jj].x), "v"(bj[jj].y), "v"(bj[jj].z), "v"(bj[jj].w));   // wait once, here
       const bool full = m0p + BM <= p.M;
       auto chunk = [&](auto CH) __attribute__((always_inline)) {
         constexpr int ch = decltype(CH)::value;
