@@ -18,7 +18,8 @@ PREC_TORCH = {PREC_F16: torch.float16, PREC_BF16: torch.bfloat16}
 
 EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_vision_workspace_bytes", "gava_vision_forward", "gava_text_workspace_bytes",
-           "gava_text_forward", "gava_similarity_head", "gava_convert_h16", "gava_debug_set_buffer"]
+           "gava_text_forward", "gava_similarity_head", "gava_convert_h16", "gava_debug_set_buffer",
+           "gava_preprocess_clip"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 
@@ -77,6 +78,13 @@ class TextModel(C.Structure):
                 ("w_tproj", _vp), ("layer", C.POINTER(TextLayer))]
 
 
+class PreprocessArgs(C.Structure):
+    _fields_ = [("frames", _vp), ("n_frames", C.c_int), ("height", C.c_int), ("width", C.c_int),
+                ("mean", C.c_float * 3), ("std", C.c_float * 3),
+                ("T", C.c_int), ("rate", C.c_int), ("size", C.c_int),
+                ("out", _fp), ("out_stride_c", C.c_int64), ("out_stride_t", C.c_int64)]
+
+
 _lib = None
 
 
@@ -115,6 +123,8 @@ def load():
     lib.gava_similarity_head.restype = C.c_int
     lib.gava_convert_h16.argtypes = [_fp, _vp, C.c_size_t, C.c_int, _vp]
     lib.gava_convert_h16.restype = C.c_int
+    lib.gava_preprocess_clip.argtypes = [C.POINTER(PreprocessArgs), _vp]
+    lib.gava_preprocess_clip.restype = C.c_int
     _lib = lib
     return lib
 
@@ -195,3 +205,16 @@ def convert_h16(x, prec):
     out = torch.empty(x.shape, dtype=h16_dtype(prec), device=x.device)
     check(load().gava_convert_h16(ptr(x), ptr(out), x.numel(), prec, stream_ptr()), "gava_convert_h16")
     return out
+
+
+def preprocess_clip(frames_u8, out, *, T, rate, size, mean, std):
+    """frames_u8: uint8 [n][H][W][3] (device); out: fp32 view [3][T][size][size] whose last two dims are contiguous."""
+    assert frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.shape[-1] == 3 and frames_u8.is_contiguous()
+    assert out.dtype == torch.float32 and tuple(out.shape) == (3, T, size, size)
+    assert out.stride(3) == 1 and out.stride(2) == size, "output planes must be contiguous"
+    a = PreprocessArgs()
+    a.frames, a.n_frames, a.height, a.width = ptr(frames_u8), frames_u8.shape[0], frames_u8.shape[1], frames_u8.shape[2]
+    a.mean, a.std = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    a.T, a.rate, a.size = T, rate, size
+    a.out, a.out_stride_c, a.out_stride_t = ptr(out), out.stride(0), out.stride(1)
+    check(load().gava_preprocess_clip(C.byref(a), stream_ptr()), "gava_preprocess_clip")

@@ -1,0 +1,58 @@
+"""GPU clip preprocessing: the evaluation branch of the reference's VideoDataset.__getitem__
+(video_dataset/dataset.py:117-139) from decoded uint8 frames to the model input, on the device.
+
+The reference does this on the CPU inside DataLoader workers: float conversion of EVERY decoded frame,
+normalisation, `F.interpolate(bilinear)`, centre crop, and only then the temporal crop.  Here the uint8
+frames go to the GPU as they are (4x fewer PCIe / HBM bytes than fp32) and one HBM-bound kernel produces
+the (3, T, size, size) clip, touching only the T frames the temporal crop keeps.  Decoding (PyAV) and the
+training-time augmentations (auto-augment, random resized crop, dataset.py:97-115) stay on the host.
+"""
+import torch
+
+from . import hip
+
+# the statistics every eval/train script passes (eval_scripts/eval_updrs.sh:9-10, k400_eval.sh:14-15)
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+class ClipPreprocessor:
+    """Mirror of VideoDataset(random_sample=False, num_spatial_views=1, num_temporal_views=1, ...).
+
+    Same argument names as the reference constructor (dataset.py:23-33) for the ones that matter here.
+    """
+
+    def __init__(self, num_frames=8, sampling_rate=1, spatial_size=224, mean=CLIP_MEAN, std=CLIP_STD,
+                 num_spatial_views=1, num_temporal_views=1):
+        if num_spatial_views != 1 or num_temporal_views != 1:
+            raise NotImplementedError("multi-view evaluation crops (dataset.py:188-199) are host-side only")
+        self.num_frames, self.sampling_rate, self.spatial_size = num_frames, sampling_rate, spatial_size
+        self.mean = tuple(float(v) for v in torch.as_tensor(mean).flatten().tolist())
+        self.std = tuple(float(v) for v in torch.as_tensor(std).flatten().tolist())
+
+    def _check(self, frames):
+        if not frames.is_cuda:
+            raise hip.GavaError("ClipPreprocessor takes device tensors (no CPU fallback)")
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+            raise ValueError("frames must be uint8 [n_frames, H, W, 3] (to_rgb().to_ndarray() order)")
+        h, w = frames.shape[1], frames.shape[2]
+        s = self.spatial_size
+        new_h, new_w = (s, w * s // h) if h < w else (h * s // w, s)
+        assert min(new_h, new_w) >= s   # dataset.py:182
+
+    def __call__(self, frames, out=None):
+        """frames: uint8 [n, H, W, 3] on the GPU -> fp32 [3, T, S, S] (dataset.py returns frames[0] of this shape)."""
+        self._check(frames)
+        T, S = self.num_frames, self.spatial_size
+        if out is None:
+            out = torch.empty(3, T, S, S, dtype=torch.float32, device=frames.device)
+        hip.preprocess_clip(frames.contiguous(), out, T=T, rate=self.sampling_rate, size=S, mean=self.mean, std=self.std)
+        return out
+
+    def batch(self, videos):
+        """list of uint8 [n_i, H_i, W_i, 3] -> fp32 [B, 3, T, S, S], each clip written in place."""
+        T, S = self.num_frames, self.spatial_size
+        x = torch.empty(len(videos), 3, T, S, S, dtype=torch.float32, device=videos[0].device)
+        for b, v in enumerate(videos):
+            self(v, out=x[b])
+        return x

@@ -191,6 +191,25 @@ int gava_similarity_head(const float* video, const float* text, const float* log
                          const float* logit_bias, int B, int C, int n_kv, int E, float* logits,
                          float* text_features, float* video_norm, gava_stream_t stream);
 
+/* Clip preprocessing of the evaluation data path (video_dataset/dataset.py:117-139, the
+ * num_spatial_views = num_temporal_views = 1 case that every eval script uses): from the decoded RGB frames of
+ * one video, uint8 [n_frames][height][width][3], to the model input slot fp32 [3][T][size][size]:
+ *   temporal crop   frame(t) = min(st + t*rate, n_frames-1), st = max(n_frames - ((T-1)*rate+1), 0) / 2
+ *                   (:163-177, a short video repeats its last frame);
+ *   value           (u8/255 - mean[c]) / std[c]                                       (:119,121);
+ *   resize          short side -> size, bilinear, align_corners=False, no antialias   (:124-133), i.e.
+ *                   src = max((dst+0.5)*in/out - 0.5, 0), taps floor(src) and min(+1, in-1);
+ *   crop            centre size x size window                                          (:181-186).
+ * out_stride_c / out_stride_t are element strides of the output (frames are contiguous size*size planes), so
+ * the kernel can write straight into clip b of a [B][3][T][size][size] batch.  HBM-bound byte work. */
+typedef struct {
+  const uint8_t* frames; int n_frames, height, width;
+  float mean[3], std[3];
+  int T, rate, size;
+  float* out; int64_t out_stride_c, out_stride_t;
+} gava_preprocess_args;
+int gava_preprocess_clip(const gava_preprocess_args* a, gava_stream_t stream);
+
 /* fp32 -> h16 conversion of a contiguous array (weight packing at load time). */
 int gava_convert_h16(const float* in, void* out, size_t n, int prec, gava_stream_t stream);
 

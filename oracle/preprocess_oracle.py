@@ -1,0 +1,35 @@
+"""TEST INFRASTRUCTURE ONLY - CPU restatement of the reference's evaluation preprocessing.
+
+Follows video_dataset/dataset.py:117-139 (+ :163-186) step by step with the same torch calls, on the CPU:
+float()/255, (x-mean)/std, permute to (C,T,H,W), F.interpolate(bilinear, align_corners=False) of ALL frames to the
+short-side size, centre crop, temporal crop.  The arithmetic inside F.interpolate is third-party (torch); the
+reference holds no fixture for it and its own dataset module cannot be imported here (needs PyAV + torchvision),
+so this restatement is pinned only by being the same torch calls in the same order: "parity unpinned" by the
+reference's own files.  Imported by tests/ only; the product (gava_clip_amd/preprocess.py) never touches it.
+"""
+import torch
+
+
+def preprocess_clip(frames_u8, num_frames, sampling_rate, spatial_size, mean, std):
+    mean = torch.as_tensor(mean, dtype=torch.float32)
+    std = torch.as_tensor(std, dtype=torch.float32)
+    frames = torch.as_tensor(frames_u8).float() / 255.                       # :118-119
+    frames = (frames - mean) / std                                           # :121
+    frames = frames.permute(3, 0, 1, 2)                                      # :122  C, T, H, W
+    if frames.size(-2) < frames.size(-1):                                    # :124-129
+        new_width = frames.size(-1) * spatial_size // frames.size(-2)
+        new_height = spatial_size
+    else:
+        new_height = frames.size(-2) * spatial_size // frames.size(-1)
+        new_width = spatial_size
+    frames = torch.nn.functional.interpolate(frames, size=(new_height, new_width), mode='bilinear',
+                                             align_corners=False)            # :130-133
+    assert min(frames.size(-2), frames.size(-1)) >= spatial_size             # :182
+    h_st = (frames.size(-2) - spatial_size) // 2                             # :183-186
+    w_st = (frames.size(-1) - spatial_size) // 2
+    frames = frames[:, :, h_st:h_st + spatial_size, w_st:w_st + spatial_size]
+    seg_len = (num_frames - 1) * sampling_rate + 1                           # :164-177, one temporal view
+    if frames.size(1) < seg_len:
+        frames = torch.cat([frames, frames[:, -1:].repeat(1, seg_len - frames.size(1), 1, 1)], dim=1)
+    st = (frames.size(1) - seg_len) // 2
+    return frames[:, st: st + num_frames * sampling_rate: sampling_rate].contiguous()

@@ -52,6 +52,16 @@ elif a.which == "attn":
     fn = lambda: hip.attention(QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, batch=BT, heads=H, n_q=n1, n_kmain=n1,
                                prec=prec, side_k=side[:, :D], side_v=side[:, D:], n_g=G, T=T, has_summary=True)
     fl = 4.0 * BT * H * n1 * cfg.attn_keys() * 64
+elif a.which == "prep":
+    from gava_clip_amd.preprocess import ClipPreprocessor
+    pre = ClipPreprocessor(num_frames=T, sampling_rate=2, spatial_size=224)
+    vids = [torch.randint(0, 256, (32, 360, 640, 3), dtype=torch.uint8, device=d, generator=g) for _ in range(a.B)]
+    X = torch.empty(a.B, 3, T, 224, 224, device=d)
+    def fn():
+        for b, v in enumerate(vids):
+            pre(v, out=X[b])
+    fl = 0.0
+    nbytes = a.B * T * 224 * 224 * (3 * 4 + 3 * (360 / 224) ** 2)   # fp32 out + the source pixels under the crop
 elif a.which == "ln":
     X, gm, bt, O = rn(R, D, dtype=torch.float32), rn(D, dtype=torch.float32), rn(D, dtype=torch.float32), torch.empty(R, D, dtype=dt, device=d)
     fn = lambda: hip.layernorm(X, gm, bt, out16=O, prec=prec); fl = 0.0
@@ -66,4 +76,7 @@ for _ in range(a.iters):
     fn()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
-print(f"{a.which}: {ms:.4f} ms/launch, {fl / ms / 1e9:.1f} TFLOP/s (B={a.B}, {a.prec})")
+if a.which == "prep":
+    print(f"prep: {ms:.4f} ms per {a.B}-clip batch ({a.B} launches), {nbytes / ms / 1e6:.1f} GB/s algorithmic")
+else:
+    print(f"{a.which}: {ms:.4f} ms/launch, {fl / ms / 1e9:.1f} TFLOP/s (B={a.B}, {a.prec})")
