@@ -312,6 +312,8 @@ class VitaCLIP(nn.Module):
         # eval-time text-feature cache: in eval mode the text tower is input
         # independent; opt-in because a benchmark must not skip work.  Invalidated by any parameter update.
         self.cache_text_features = False
+        self.text_on_side_stream = os.environ.get("GAVA_TEXT_STREAM", "1") != "0"
+        self._text_stream = None
         self._text_cache = None
         self.gather_across_ranks = True     # RCCL all-gather of clip embeddings when world_size > 1
         self.debug_taps = False             # keep per-layer CLS rows of the last forward
@@ -491,8 +493,11 @@ class VitaCLIP(nn.Module):
         lib = hip.load()
         B, Cc, T, Hh, Ww = x.size()
         sh = self._shape
-        cls_x, summary = self.encode_video(x)
-        video = self._gather(cls_x)
+        if not x.is_cuda:
+            raise hip.GavaError("VitaCLIP (gava_clip_amd) runs on the HIP device only: move the model and the "
+                                "input with .cuda(); there is no CPU fallback")
+        text, text_stream = None, None
+        self._pack()   # (re)pack weights on the caller's stream, before any fork
         if self.use_text_prompt_learning:
             if desc_wise:
                 assert self.training == False
@@ -500,10 +505,26 @@ class VitaCLIP(nn.Module):
             if key is not None and self._text_cache is not None and self._text_cache[0] == key:
                 text = self._text_cache[1]
             else:
-                text = self.encode_text()
+                # The text tower does not depend on the clip: it runs on its own HIP stream beside the
+                # vision tower (its few-workgroup kernels slot in between the big GEMMs) and joins at the head.
+                main = torch.cuda.current_stream(x.device)
+                if self.text_on_side_stream:
+                    if self._text_stream is None or self._text_stream.device != x.device:
+                        self._text_stream = torch.cuda.Stream(device=x.device)
+                    text_stream = self._text_stream
+                    text_stream.wait_stream(main)
+                    with torch.cuda.stream(text_stream):
+                        text = self.encode_text()
+                else:
+                    text = self.encode_text()
                 self._text_cache = (key, text) if key is not None else None
         else:
             text = self.text_features.to(device=x.device, dtype=torch.float32).contiguous()
+        cls_x, summary = self.encode_video(x)
+        if text_stream is not None:
+            torch.cuda.current_stream(x.device).wait_stream(text_stream)
+            text.record_stream(torch.cuda.current_stream(x.device))
+        video = self._gather(cls_x)
         Bg, Cn = video.shape[0], text.shape[0]
         logits = torch.empty(Bg, Cn, dtype=torch.float32, device=x.device)
         tfeat = torch.empty(Cn, sh["E"], dtype=torch.float32, device=x.device)
