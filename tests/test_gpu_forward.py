@@ -170,3 +170,33 @@ def test_eval_text_feature_cache_is_exact_and_invalidated():
         m.train()
         m(x)
         assert m._text_cache is None
+
+
+def test_forward_is_hipgraph_capturable_and_side_streams_join():
+    """The C ABI allocates and synchronises nothing (include/gava_hip.h, conventions): a whole forward - the
+    vision driver with its prompt-path side stream, the text tower on its own stream, the head - can be captured
+    into one hipGraph, and the replay reproduces the eager logits bit for bit.  Also pins text-on-side-stream
+    == text-on-main-stream."""
+    m, _ = build(TINY)
+    m.debug_taps = False
+    x = torch.from_numpy(synth.synth_clip(2, TINY.num_frames, TINY.input_size)).cuda()
+    with torch.no_grad():
+        ref = m(x)[0].clone()
+        m.text_on_side_stream = False
+        assert torch.equal(m(x)[0], ref)
+        m.text_on_side_stream = True
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m(x)                                  # warm-up on a non-default stream (workspaces, packed weights)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = m(x)[0]
+        x.copy_(torch.from_numpy(synth.synth_clip(2, TINY.num_frames, TINY.input_size, seed=77)).cuda())
+        g.replay()
+        torch.cuda.synchronize()
+        got = out.clone()
+        want = m(x)[0]
+    assert torch.equal(got, want)
+    assert not torch.equal(got, ref)
