@@ -1,0 +1,242 @@
+// backward.hip — gradient kernels for the trainable subset (training/train.py:441-490 calls
+// loss.backward() through VitaCLIP.forward; every transformer weight is frozen, VitaCLIP_model.py:230-239, so the
+// path needs dgrad only: gradients flow THROUGH the frozen GEMMs to the prompt parameters).
+//   * dgrad GEMMs are gava_gemm on transposed weight copies (dX = dY . W  ==  gemm(A = dY, W = W^T [in][out])).
+//   * this file: LayerNorm backward, QuickGELU backward, softmax-attention backward.
+// Gradient operands are bf16 (fp32 range: no loss scaling needed inside the library), accumulation fp32.
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int MAXV = 4;  // float4 per lane: D <= 1024
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward, one wave per row.  y = xhat * gamma + beta, xhat = (x - mean) * rstd (eps 1e-5):
+//   g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dgamma += dy * xhat;  dbeta += dy
+struct LnBwdParams {
+  const float* x; long x_stride; const int* x_idx;      // forward input rows (optionally gathered)
+  const float* gamma;
+  const float* dy; long dy_stride;
+  float* dx; long dx_stride; const int* dx_idx;         // optionally scattered
+  float* dgamma; float* dbeta;                          // optional, fp32 [D], accumulated with atomics
+  int rows, D, accumulate;
+};
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LnBwdParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const float* xr = p.x + (p.x_idx ? (long)p.x_idx[row] : (long)row) * p.x_stride;
+  const float* dyr = p.dy + (long)row * p.dy_stride;
+  float4 v[MAXV], g[MAXV], d[MAXV];
+  bool act[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    act[i] = c < p.D;
+    if (act[i]) {
+      v[i] = *reinterpret_cast<const float4*>(xr + c);
+      d[i] = *reinterpret_cast<const float4*>(dyr + c);
+      g[i] = *reinterpret_cast<const float4*>(p.gamma + c);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float inv = 1.f / (float)p.D;
+  const float mean = wave_sum(s) * inv;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (act[i]) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * inv + 1e-5f);
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (act[i]) {
+      v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;   // xhat
+      if (p.dgamma) {
+        const int c = (lane + 64 * i) * 4;
+        atomicAdd(p.dgamma + c, d[i].x * v[i].x); atomicAdd(p.dgamma + c + 1, d[i].y * v[i].y);
+        atomicAdd(p.dgamma + c + 2, d[i].z * v[i].z); atomicAdd(p.dgamma + c + 3, d[i].w * v[i].w);
+        atomicAdd(p.dbeta + c, d[i].x); atomicAdd(p.dbeta + c + 1, d[i].y);
+        atomicAdd(p.dbeta + c + 2, d[i].z); atomicAdd(p.dbeta + c + 3, d[i].w);
+      }
+      g[i].x *= d[i].x; g[i].y *= d[i].y; g[i].z *= d[i].z; g[i].w *= d[i].w;   // g = dy * gamma
+      sg += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      sgx += (g[i].x * v[i].x + g[i].y * v[i].y) + (g[i].z * v[i].z + g[i].w * v[i].w);
+    }
+  const float mg = wave_sum(sg) * inv, mgx = wave_sum(sgx) * inv;
+  float* dxr = p.dx + (p.dx_idx ? (long)p.dx_idx[row] : (long)row) * p.dx_stride;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (act[i]) {
+      const int c = (lane + 64 * i) * 4;
+      float4 o;
+      o.x = rstd * (g[i].x - mg - v[i].x * mgx); o.y = rstd * (g[i].y - mg - v[i].y * mgx);
+      o.z = rstd * (g[i].z - mg - v[i].z * mgx); o.w = rstd * (g[i].w - mg - v[i].w * mgx);
+      if (p.accumulate) {
+        const float4 old = *reinterpret_cast<const float4*>(dxr + c);
+        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+      }
+      *reinterpret_cast<float4*>(dxr + c) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// QuickGELU backward: y = x * s, s = sigmoid(1.702 x)  =>  dy/dx = s * (1 + 1.702 x (1 - s))
+template <class P>
+__global__ __launch_bounds__(256) void qgelu_bwd_kernel(const unsigned short* pre, const unsigned short* dh,
+                                                         unsigned short* dpre, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const uint2 a = reinterpret_cast<const uint2*>(pre)[i];
+    const uint2 b = reinterpret_cast<const uint2*>(dh)[i];
+    float x[4] = {P::up((unsigned short)a.x), P::up((unsigned short)(a.x >> 16)), P::up((unsigned short)a.y), P::up((unsigned short)(a.y >> 16))};
+    float d[4] = {P::up((unsigned short)b.x), P::up((unsigned short)(b.x >> 16)), P::up((unsigned short)b.y), P::up((unsigned short)(b.y >> 16))};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float s = 1.f / (1.f + __expf(-1.702f * x[e]));
+      d[e] *= s * (1.f + 1.702f * x[e] * (1.f - s));
+    }
+    reinterpret_cast<uint2*>(dpre)[i] = pack4<P>(d[0], d[1], d[2], d[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention backward, short sequences (n <= 88 keys; the text tower's 77).  One workgroup per (sequence, head):
+//   S = Q K^T (Q already carries 1/sqrt(dh)), P = softmax(S + mask), O = P V
+//   dV = P^T dO;  dP = dO V^T;  dS = P * (dP - rowsum(P * dP));  dQ = q_scale * dS K;  dK = dS^T Q
+// Everything fp32 in LDS/registers: 5 products of n x n x 64 are ~2 MFLOP per head, not worth MFMA tiles;
+// the vision-side (n = 214, 6144 heads per layer) version is MFMA work of its own.
+constexpr int ATT_BWD_MAXN = 88, DH = 64;   // 154 KiB of LDS at n = 88
+
+struct AttnBwdParams {
+  const unsigned short* q; const unsigned short* k; const unsigned short* v; long ld_qkv;
+  const unsigned short* dout; long ld_dout;
+  unsigned short* dq; unsigned short* dk; unsigned short* dv; long ld_dqkv;
+  int heads, n, causal;
+  float q_scale;
+};
+
+template <class P>
+__global__ __launch_bounds__(256) void attention_bwd_small_kernel(const AttnBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int n = p.n, tid = threadIdx.x;
+  const int b = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
+  float* Q = reinterpret_cast<float*>(smem_raw);         // [n][DH+1] each (padded: conflict-free column walks)
+  constexpr int LDT = DH + 1;
+  float* K = Q + n * LDT;
+  float* V = K + n * LDT;
+  float* dO = V + n * LDT;
+  float* Pm = dO + n * LDT;                               // [n][n+1]  P, then dS
+  float* dP = Pm + n * (n + 1);                           // [n][n+1]
+  const int LDP = n + 1;
+  const long row0 = (long)b * n;
+  for (int e = tid; e < n * DH; e += 256) {
+    const int i = e / DH, d = e % DH;
+    const long r = row0 + i;
+    Q[i * LDT + d] = P::up(p.q[r * p.ld_qkv + h * DH + d]);
+    K[i * LDT + d] = P::up(p.k[r * p.ld_qkv + h * DH + d]);
+    V[i * LDT + d] = P::up(p.v[r * p.ld_qkv + h * DH + d]);
+    dO[i * LDT + d] = P::up(p.dout[r * p.ld_dout + h * DH + d]);
+  }
+  __syncthreads();
+  // S and dP
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e / n, j = e % n;
+    float s = 0.f, t = 0.f;
+    if (!p.causal || j <= i) {
+#pragma unroll 16
+      for (int d = 0; d < DH; ++d) { s += Q[i * LDT + d] * K[j * LDT + d]; t += dO[i * LDT + d] * V[j * LDT + d]; }
+    } else {
+      s = -INFINITY;
+    }
+    Pm[i * LDP + j] = s; dP[i * LDP + j] = t;
+  }
+  __syncthreads();
+  // row softmax and dS, one wave per row
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int i = wave; i < n; i += 4) {
+    float m = -INFINITY;
+    for (int j = lane; j < n; j += 64) m = fmaxf(m, Pm[i * LDP + j]);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.f;
+    for (int j = lane; j < n; j += 64) { const float e = __expf(Pm[i * LDP + j] - m); Pm[i * LDP + j] = e; sum += e; }
+    sum = wave_sum(sum);
+    const float r = 1.f / sum;
+    float delta = 0.f;
+    for (int j = lane; j < n; j += 64) { const float pj = Pm[i * LDP + j] * r; Pm[i * LDP + j] = pj; delta += pj * dP[i * LDP + j]; }
+    delta = wave_sum(delta);
+    // dP row becomes dS; the P row is kept for dV
+    for (int j = lane; j < n; j += 64) dP[i * LDP + j] = Pm[i * LDP + j] * (dP[i * LDP + j] - delta);
+  }
+  __syncthreads();
+  // dQ[i][d] = q_scale * sum_j dS[i][j] K[j][d];  dK[j][d] = sum_i dS[i][j] Q[i][d];  dV[j][d] = sum_i P[i][j] dO[i][d]
+  for (int e = tid; e < n * DH; e += 256) {
+    const int i = e / DH, d = e % DH;
+    float aq = 0.f, ak = 0.f, av = 0.f;
+    for (int j = 0; j < n; ++j) {
+      aq += dP[i * LDP + j] * K[j * LDT + d];
+      ak += dP[j * LDP + i] * Q[j * LDT + d];
+      av += Pm[j * LDP + i] * dO[j * LDT + d];
+    }
+    const long r = row0 + i;
+    p.dq[r * p.ld_dqkv + h * DH + d] = P::cvt(aq * p.q_scale);
+    p.dk[r * p.ld_dqkv + h * DH + d] = P::cvt(ak);
+    p.dv[r * p.ld_dqkv + h * DH + d] = P::cvt(av);
+  }
+}
+
+}  // namespace
+
+extern "C" int gava_layernorm_backward(const gava_layernorm_bwd_args* a, gava_stream_t stream) {
+  if (!a || !a->x || !a->gamma || !a->dy || !a->dx) return GAVA_EINVAL;
+  if (a->rows <= 0 || a->D <= 0 || a->D % 4 || a->D > MAXV * 256) return GAVA_EINVAL;
+  if ((a->dgamma == nullptr) != (a->dbeta == nullptr)) return GAVA_EINVAL;
+  if (a->x_stride % 4 || a->dy_stride % 4 || a->dx_stride % 4) return GAVA_EINVAL;
+  LnBwdParams p{a->x, a->x_stride, a->x_row_index, a->gamma, a->dy, a->dy_stride, a->dx, a->dx_stride,
+                a->dx_row_index, a->dgamma, a->dbeta, a->rows, a->D, a->accumulate};
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+extern "C" int gava_qgelu_backward(const void* pre, const void* dh, void* dpre, size_t n, int prec, gava_stream_t stream) {
+  if (!pre || !dh || !dpre || n % 4) return GAVA_EINVAL;
+  if (n == 0) return GAVA_OK;
+  const size_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == GAVA_PREC_F16)
+    hipLaunchKernelGGL(qgelu_bwd_kernel<PrecF16>, dim3(blocks), dim3(256), 0, s, (const unsigned short*)pre, (const unsigned short*)dh, (unsigned short*)dpre, n4);
+  else if (prec == GAVA_PREC_BF16)
+    hipLaunchKernelGGL(qgelu_bwd_kernel<PrecBF16>, dim3(blocks), dim3(256), 0, s, (const unsigned short*)pre, (const unsigned short*)dh, (unsigned short*)dpre, n4);
+  else return GAVA_EINVAL;
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+extern "C" int gava_attention_backward(const gava_attention_bwd_args* a, gava_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->v || !a->dout || !a->dq || !a->dk || !a->dv) return GAVA_EINVAL;
+  if (a->batch <= 0 || a->heads <= 0 || a->n <= 0 || a->n > ATT_BWD_MAXN) return GAVA_EINVAL;
+  AttnBwdParams p{(const unsigned short*)a->q, (const unsigned short*)a->k, (const unsigned short*)a->v, a->ld_qkv,
+                  (const unsigned short*)a->dout, a->ld_dout, (unsigned short*)a->dq, (unsigned short*)a->dk,
+                  (unsigned short*)a->dv, a->ld_dqkv, a->heads, a->n, a->causal, a->q_scale};
+  const size_t lds = (size_t)(4 * a->n * (DH + 1) + 2 * a->n * (a->n + 1)) * sizeof(float);
+  if (lds > 160 * 1024) return GAVA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(a->batch * a->heads), block(256);
+  if (a->prec == GAVA_PREC_F16) {
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)attention_bwd_small_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GAVA_ELAUNCH;
+    hipLaunchKernelGGL(attention_bwd_small_kernel<PrecF16>, grid, block, lds, s, p);
+  } else if (a->prec == GAVA_PREC_BF16) {
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)attention_bwd_small_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GAVA_ELAUNCH;
+    hipLaunchKernelGGL(attention_bwd_small_kernel<PrecBF16>, grid, block, lds, s, p);
+  } else return GAVA_EINVAL;
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}

@@ -273,6 +273,12 @@ extern "C" size_t gava_text_workspace_bytes(const gava_text_model* m) {
 extern "C" int gava_text_forward(const gava_text_model* m, const int32_t* tokens, const float* ctx,
                                  const int32_t* eot_index, float* out, void* workspace, size_t workspace_bytes,
                                  gava_stream_t stream) {
+  return gava_text_forward_train(m, tokens, ctx, eot_index, out, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gava_text_forward_train(const gava_text_model* m, const int32_t* tokens, const float* ctx,
+                                       const int32_t* eot_index, float* out, float* saved_x, void* workspace,
+                                       size_t workspace_bytes, gava_stream_t stream) {
   TRY(check_text(m));
   if (!tokens || !ctx || !eot_index || !out || !workspace) return GAVA_EINVAL;
   const TextWs w = carve_text(m, workspace, workspace_bytes);
@@ -281,8 +287,14 @@ extern "C" int gava_text_forward(const gava_text_model* m, const int32_t* tokens
   const int R = m->n_prompts * m->L, W = m->W, pr = m->prec;
   const int sp = m->split ? 1 : 0, S = sp ? 3 : 1;  // split precision: A rows are [hi|lo|hi], K' = 3K
   TRY(gava::text_embed(m->token_embedding, m->positional_embedding, ctx, tokens, w.X, m->n_prompts, m->L, W, m->n_ctx, s));
+  auto keep = [&](int i) -> int {   // training: the input of block i (i == layers: the final stream)
+    if (!saved_x) return GAVA_OK;
+    return hipMemcpyAsync(saved_x + (size_t)i * R * W, w.X, (size_t)R * W * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess
+               ? GAVA_OK : GAVA_ELAUNCH;
+  };
   for (int i = 0; i < m->layers; ++i) {
     const gava_text_layer& L = m->layer[i];
+    TRY(keep(i));
     TRY(ln(w.X, W, nullptr, L.ln1_g, L.ln1_b, w.Xn, S * W, nullptr, 0, R, W, pr, stream, sp));
     TRY(gemm(w.Xn, S * W, L.w_qkv, S * W, L.b_qkv, w.QKV, 3 * W, R, 3 * W, S * W, GAVA_EPI_H16, pr, stream, nullptr, 0, W, 0.125f));
     {
@@ -298,6 +310,7 @@ extern "C" int gava_text_forward(const gava_text_model* m, const int32_t* tokens
     TRY(gemm(w.Xn, S * W, L.w_fc, S * W, L.b_fc, w.HID, S * 4 * W, R, 4 * W, S * W, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, sp));
     TRY(gemm(w.HID, S * 4 * W, L.w_proj, S * 4 * W, L.b_proj, w.X, W, R, W, S * 4 * W, GAVA_EPI_F32, pr, stream, w.X, W));
   }
+  TRY(keep(m->layers));
   // ln_final on the EOT rows only, then text_projection (VitaCLIP_text_encoder.py:164-169)
   TRY(ln(w.X, W, eot_index, m->lnf_g, m->lnf_b, w.EOT16, S * W, nullptr, 0, m->n_prompts, W, pr, stream, sp));
   TRY(gemm(w.EOT16, S * W, m->w_tproj, S * W, nullptr, out, m->E, m->n_prompts, m->E, S * W, GAVA_EPI_F32, pr, stream));

@@ -19,7 +19,8 @@ PREC_TORCH = {PREC_F16: torch.float16, PREC_BF16: torch.bfloat16}
 EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_vision_workspace_bytes", "gava_vision_forward", "gava_text_workspace_bytes",
            "gava_text_forward", "gava_similarity_head", "gava_convert_h16", "gava_debug_set_buffer",
-           "gava_preprocess_clip"]
+           "gava_preprocess_clip", "gava_layernorm_backward", "gava_qgelu_backward", "gava_attention_backward",
+           "gava_text_forward_train"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 
@@ -85,6 +86,20 @@ class PreprocessArgs(C.Structure):
                 ("out", _fp), ("out_stride_c", C.c_int64), ("out_stride_t", C.c_int64)]
 
 
+class LayerNormBwdArgs(C.Structure):
+    _fields_ = [("x", _fp), ("x_stride", C.c_int64), ("x_row_index", _ip), ("gamma", _fp),
+                ("dy", _fp), ("dy_stride", C.c_int64),
+                ("dx", _fp), ("dx_stride", C.c_int64), ("dx_row_index", _ip),
+                ("dgamma", _fp), ("dbeta", _fp), ("rows", C.c_int), ("D", C.c_int), ("accumulate", C.c_int)]
+
+
+class AttentionBwdArgs(C.Structure):
+    _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("ld_qkv", C.c_int64), ("dout", _vp), ("ld_dout", C.c_int64),
+                ("dq", _vp), ("dk", _vp), ("dv", _vp), ("ld_dqkv", C.c_int64),
+                ("batch", C.c_int), ("heads", C.c_int), ("n", C.c_int), ("causal", C.c_int), ("prec", C.c_int),
+                ("q_scale", C.c_float)]
+
+
 _lib = None
 
 
@@ -125,6 +140,14 @@ def load():
     lib.gava_convert_h16.restype = C.c_int
     lib.gava_preprocess_clip.argtypes = [C.POINTER(PreprocessArgs), _vp]
     lib.gava_preprocess_clip.restype = C.c_int
+    lib.gava_layernorm_backward.argtypes = [C.POINTER(LayerNormBwdArgs), _vp]
+    lib.gava_layernorm_backward.restype = C.c_int
+    lib.gava_qgelu_backward.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp]
+    lib.gava_qgelu_backward.restype = C.c_int
+    lib.gava_attention_backward.argtypes = [C.POINTER(AttentionBwdArgs), _vp]
+    lib.gava_attention_backward.restype = C.c_int
+    lib.gava_text_forward_train.argtypes = [C.POINTER(TextModel), _ip, _fp, _ip, _fp, _fp, _vp, C.c_size_t, _vp]
+    lib.gava_text_forward_train.restype = C.c_int
     _lib = lib
     return lib
 
@@ -218,3 +241,30 @@ def preprocess_clip(frames_u8, out, *, T, rate, size, mean, std):
     a.T, a.rate, a.size = T, rate, size
     a.out, a.out_stride_c, a.out_stride_t = ptr(out), out.stride(0), out.stride(1)
     check(load().gava_preprocess_clip(C.byref(a), stream_ptr()), "gava_preprocess_clip")
+
+
+# ---- backward ops ------------------------------------------------------------
+
+def layernorm_backward(x, gamma, dy, dx, *, accumulate=False, x_row_index=None, dx_row_index=None, rows=None,
+                       dgamma=None, dbeta=None):
+    a = LayerNormBwdArgs()
+    a.x, a.x_stride, a.x_row_index = ptr(x), x.stride(0), ptr(x_row_index)
+    a.gamma, a.dy, a.dy_stride = ptr(gamma), ptr(dy), dy.stride(0)
+    a.dx, a.dx_stride, a.dx_row_index = ptr(dx), dx.stride(0), ptr(dx_row_index)
+    a.dgamma, a.dbeta = ptr(dgamma), ptr(dbeta)
+    a.rows, a.D, a.accumulate = (dy.shape[0] if rows is None else rows), x.shape[-1], int(accumulate)
+    check(load().gava_layernorm_backward(C.byref(a), stream_ptr()), "gava_layernorm_backward")
+
+
+def qgelu_backward(pre, dh, dpre, prec):
+    assert pre.is_contiguous() and dh.is_contiguous() and dpre.is_contiguous() and pre.numel() == dh.numel() == dpre.numel()
+    check(load().gava_qgelu_backward(ptr(pre), ptr(dh), ptr(dpre), pre.numel(), prec, stream_ptr()), "gava_qgelu_backward")
+
+
+def attention_backward(q, k, v, dout, dq, dk, dv, *, batch, heads, n, prec, causal=False, q_scale=1.0):
+    a = AttentionBwdArgs()
+    a.q, a.k, a.v, a.ld_qkv = ptr(q), ptr(k), ptr(v), q.stride(0)
+    a.dout, a.ld_dout = ptr(dout), dout.stride(0)
+    a.dq, a.dk, a.dv, a.ld_dqkv = ptr(dq), ptr(dk), ptr(dv), dq.stride(0)
+    a.batch, a.heads, a.n, a.causal, a.prec, a.q_scale = batch, heads, n, int(causal), prec, q_scale
+    check(load().gava_attention_backward(C.byref(a), stream_ptr()), "gava_attention_backward")

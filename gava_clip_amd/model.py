@@ -331,9 +331,27 @@ class VitaCLIP(nn.Module):
         self.prec = hip.PREC_NAMES[name]
         self._packed = None
 
+    _PASS_THROUGH = ("prompt_learner.ctx", "logit_scale", "global_prompts", "local_prompts", "token_embedding",
+                     "pos_embed", "time_embed", "positional_embedding", "cls_token")
+
     def _pack_key(self):
-        ps = list(self.parameters())
-        return (self.prec, self.text_split_precision, ps[0].device, ps[0].data_ptr(), sum(p._version for p in ps))
+        """Changes when a packed 16-bit copy goes stale.  fp32 pass-through parameters (prompts, embeddings, LN
+        affines, biases: the structs hold pointers into their own storage) only count by address, so an optimizer
+        step on the prompt parameters does not re-convert 180 M frozen weights."""
+        ver, addr = 0, 0
+        for name, p in self.named_parameters():
+            addr ^= p.data_ptr()
+            if p.dim() >= 2 and not any(k in name for k in self._PASS_THROUGH):
+                ver += p._version
+        ps = next(self.parameters())
+        return (self.prec, self.text_split_precision, ps.device, addr, ver)
+
+    def _pack_text_backward(self):
+        from . import training
+        key = self._pack_key()
+        if getattr(self, "_bwd_pack", None) is None or self._bwd_pack[0] != key:
+            self._bwd_pack = (key, training.pack_text_backward(self))
+        return self._bwd_pack[1]
 
     def _h16(self, t):
         return hip.convert_h16(t.detach().float(), self.prec)
@@ -488,6 +506,19 @@ class VitaCLIP(nn.Module):
         dist.all_gather_into_tensor(out, feats)
         return out
 
+    def _train_head(self, video, text, summary, desc_wise):
+        """Similarity head under autograd (VitaCLIP_model.py:248,255,287-293,308-309): 2*B*C*E flop on (B,E)/(C,E)
+        tensors, traced by torch so that d logits reaches the text tower's backward and logit_scale."""
+        assert not desc_wise
+        vf = video / video.norm(dim=-1, keepdim=True)
+        tf = text / text.norm(dim=-1, keepdim=True)
+        logits = self.logit_scale.exp() * vf @ tf.t()
+        if self.logit_bias is not None:
+            logits = logits + self.logit_bias
+        self.text_features = tf / tf.norm(dim=-1, keepdim=True)
+        self.last.update(video_features=vf.detach(), summary=summary)
+        return logits, None, None
+
     # ---- forward ------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, memory=None, video_nte=None, desc_wise=False):
         lib = hip.load()
@@ -502,7 +533,12 @@ class VitaCLIP(nn.Module):
             if desc_wise:
                 assert self.training == False
             key = self._pack_key() if (self.cache_text_features and not self.training) else None
-            if key is not None and self._text_cache is not None and self._text_cache[0] == key:
+            train_text = torch.is_grad_enabled() and self.prompt_learner.ctx.requires_grad
+            if train_text:
+                # differentiable text tower (gava_clip_amd/training.py): HIP kernels in both directions
+                from .training import TextTowerFn
+                text = TextTowerFn.apply(self, self.prompt_learner.ctx)
+            elif key is not None and self._text_cache is not None and self._text_cache[0] == key:
                 text = self._text_cache[1]
             else:
                 # The text tower does not depend on the clip: it runs on its own HIP stream beside the
@@ -525,6 +561,10 @@ class VitaCLIP(nn.Module):
             torch.cuda.current_stream(x.device).wait_stream(text_stream)
             text.record_stream(torch.cuda.current_stream(x.device))
         video = self._gather(cls_x)
+        if torch.is_grad_enabled() and (text.requires_grad or self.logit_scale.requires_grad):
+            if (self.add_nte and video_nte is not None) or (self.use_support_memory and memory is not None):
+                raise NotImplementedError("auxiliary heads under autograd (SURVEY §8f row 4)")
+            return self._train_head(video, text, summary, desc_wise)
         Bg, Cn = video.shape[0], text.shape[0]
         logits = torch.empty(Bg, Cn, dtype=torch.float32, device=x.device)
         tfeat = torch.empty(Cn, sh["E"], dtype=torch.float32, device=x.device)

@@ -191,6 +191,46 @@ int gava_similarity_head(const float* video, const float* text, const float* log
                          const float* logit_bias, int B, int C, int n_kv, int E, float* logits,
                          float* text_features, float* video_norm, gava_stream_t stream);
 
+/* ---- Backward of the trainable subset (training/train.py:441-490) --------------------------
+ * Every transformer weight of the reference is frozen (VitaCLIP_model.py:230-239): the gradient only has to flow
+ * THROUGH the GEMMs to the prompt parameters.  dgrad is gava_gemm on a transposed weight copy
+ * (dX = dY . W == gemm(A = dY, W = W^T stored [in][out])); the three kernels below are the rest of the chain.
+ * Gradient operands are 16-bit (bf16 recommended: fp32 range), accumulation and LayerNorm arithmetic fp32. */
+
+/* LayerNorm backward (torch.nn.functional.layer_norm, eps 1e-5): dx = rstd*(g - mean(g) - xhat*mean(g*xhat)),
+ * g = dy*gamma.  x rows may be gathered (x_row_index) and dx rows scattered (dx_row_index); accumulate != 0 adds
+ * into dx (the residual branch).  dgamma/dbeta (both or neither) are accumulated with atomics. */
+typedef struct {
+  const float* x; int64_t x_stride; const int32_t* x_row_index;
+  const float* gamma;
+  const float* dy; int64_t dy_stride;
+  float* dx; int64_t dx_stride; const int32_t* dx_row_index;
+  float* dgamma; float* dbeta;
+  int rows, D, accumulate;
+} gava_layernorm_bwd_args;
+int gava_layernorm_backward(const gava_layernorm_bwd_args* a, gava_stream_t stream);
+
+/* QuickGELU backward: dpre = dh * s*(1 + 1.702*pre*(1-s)), s = sigmoid(1.702*pre); h16 in/out, n % 4 == 0. */
+int gava_qgelu_backward(const void* pre, const void* dh, void* dpre, size_t n, int prec, gava_stream_t stream);
+
+/* Softmax-attention backward for short sequences (n <= 88: the text tower, nn.MultiheadAttention at
+ * VitaCLIP_text_encoder.py:71,83).  q (already scaled by 1/sqrt(dh)), k, v, dout: h16 rows [batch*n][ld], head h at
+ * columns [64h, 64h+64).  Writes dq (times q_scale, the factor folded into q), dk, dv. */
+typedef struct {
+  const void* q; const void* k; const void* v; int64_t ld_qkv;
+  const void* dout; int64_t ld_dout;
+  void* dq; void* dk; void* dv; int64_t ld_dqkv;
+  int batch, heads, n, causal, prec;
+  float q_scale;
+} gava_attention_bwd_args;
+int gava_attention_backward(const gava_attention_bwd_args* a, gava_stream_t stream);
+
+/* gava_text_forward that also keeps what the backward recomputes from: saved_x fp32 [layers+1][n_prompts*L][W] =
+ * the input of every residual block and the final stream (before ln_final). */
+int gava_text_forward_train(const gava_text_model* m, const int32_t* tokens, const float* ctx,
+                            const int32_t* eot_index, float* out, float* saved_x, void* workspace,
+                            size_t workspace_bytes, gava_stream_t stream);
+
 /* Clip preprocessing of the evaluation data path (video_dataset/dataset.py:117-139, the
  * num_spatial_views = num_temporal_views = 1 case that every eval script uses): from the decoded RGB frames of
  * one video, uint8 [n_frames][height][width][3], to the model input slot fp32 [3][T][size][size]:

@@ -1,0 +1,138 @@
+"""GPU: backward kernels and the text-side training path against torch autograd / the oracle.
+
+Tolerances: LayerNorm backward is fp32 arithmetic -> 1e-5 of the gradient's range.  QuickGELU / attention
+backward take bf16 operands (8-bit mantissa): inputs are rounded to bf16 first, so what is left is the output
+rounding, 2^-8 relative.  The end-to-end gradient of the context vectors goes through 12 blocks with bf16
+operands on our side and fp32 in the oracle: norm-wise 3e-2."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gava_clip_amd import VitaCLIP, hip, synth  # noqa: E402
+from gava_clip_amd.config import TINY, VIT_B16_T8  # noqa: E402
+from oracle.vita_oracle import Oracle  # noqa: E402  (checker only)
+from helpers import CLASSES_3, model_kwargs, synth_torch_state  # noqa: E402
+
+BF = hip.PREC_BF16
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+@pytest.mark.parametrize("rows,D", [(9, 128), (231, 512), (40, 768), (5, 1024)])
+def test_layernorm_backward_matches_autograd(rows, D):
+    g = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.3).requires_grad_()
+    gamma = (torch.rand(D, generator=g) + 0.5).requires_grad_()
+    beta = torch.randn(D, generator=g).requires_grad_()
+    dy = torch.randn(rows, D, generator=g)
+    torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-5).backward(dy)
+    xd, dyd = x.detach().cuda(), dy.cuda()
+    base = torch.randn(rows, D, generator=g).cuda()
+    dx = base.clone()
+    dgm, dbt = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    hip.layernorm_backward(xd, gamma.detach().cuda(), dyd, dx, accumulate=True, dgamma=dgm, dbeta=dbt)
+    assert (dx.cpu() - base.cpu() - x.grad).abs().max() <= 1e-5 * x.grad.abs().max() + 1e-6
+    assert (dgm.cpu() - gamma.grad).abs().max() <= 1e-4 * gamma.grad.abs().max()
+    assert (dbt.cpu() - beta.grad).abs().max() <= 1e-4 * beta.grad.abs().max()
+
+
+def test_layernorm_backward_gather_scatter_rows():
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(50, 256, generator=g)
+    idx = torch.tensor([7, 30, 49], dtype=torch.int32)
+    gamma = torch.rand(256, generator=g) + 0.5
+    dy = torch.randn(3, 256, generator=g)
+    xs = X[idx.long()].clone().requires_grad_()
+    torch.nn.functional.layer_norm(xs, (256,), gamma, torch.zeros(256), 1e-5).backward(dy)
+    dX = torch.zeros(50, 256, device="cuda")
+    hip.layernorm_backward(X.cuda(), gamma.cuda(), dy.cuda(), dX, x_row_index=idx.cuda(), dx_row_index=idx.cuda(), rows=3)
+    ref = torch.zeros(50, 256)
+    ref[idx.long()] = xs.grad
+    assert (dX.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
+
+
+def test_qgelu_backward_matches_autograd():
+    g = torch.Generator().manual_seed(5)
+    pre = (torch.randn(231, 2048, generator=g) * 2).bfloat16()
+    dh = torch.randn(231, 2048, generator=g).bfloat16()
+    x = pre.float().requires_grad_()
+    (x * torch.sigmoid(1.702 * x)).backward(dh.float())
+    out = torch.empty_like(pre, device="cuda")
+    hip.qgelu_backward(pre.cuda(), dh.cuda(), out, BF)
+    assert (out.float().cpu() - x.grad).abs().max() <= 2 ** -8 * x.grad.abs().max() * 1.01
+
+
+@pytest.mark.parametrize("batch,heads,n,causal", [(3, 8, 77, True), (2, 2, 77, False), (4, 3, 8, True), (1, 1, 88, True), (5, 2, 1, True)])
+def test_attention_backward_small_matches_autograd(batch, heads, n, causal):
+    g = torch.Generator().manual_seed(n * 7 + heads)
+    W = heads * 64
+    qkv = torch.randn(batch * n, 3 * W, generator=g).bfloat16()
+    do = torch.randn(batch * n, W, generator=g).bfloat16()
+    q, k, v = [t.float().view(batch, n, heads, 64).transpose(1, 2).requires_grad_() for t in qkv.split(W, dim=1)]
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((n, n), float("-inf")).triu_(1)
+    o = s.softmax(-1) @ v
+    o.backward(do.float().view(batch, n, heads, 64).transpose(1, 2))
+    # the kernel takes q already scaled (as the forward's QKV GEMM writes it) and folds the scale back into dq
+    qkv_s = qkv.float().clone()
+    qkv_s[:, :W] *= 0.125          # exact in bf16 (power of two)
+    qd = qkv_s.bfloat16().cuda()
+    dqkv = torch.empty(batch * n, 3 * W, dtype=torch.bfloat16, device="cuda")
+    hip.attention_backward(qd[:, :W], qd[:, W:2 * W], qd[:, 2 * W:], do.cuda(), dqkv[:, :W], dqkv[:, W:2 * W], dqkv[:, 2 * W:],
+                           batch=batch, heads=heads, n=n, prec=BF, causal=causal, q_scale=0.125)
+    for name, grad, sl in (("dq", q.grad, slice(0, W)), ("dk", k.grad, slice(W, 2 * W)), ("dv", v.grad, slice(2 * W, 3 * W))):
+        ref = grad.transpose(1, 2).reshape(batch * n, W)
+        got = dqkv[:, sl].float().cpu()
+        assert (got - ref).abs().max() <= 2 ** -8 * ref.abs().max() * 1.05 + 1e-6, name
+
+
+def _oracle_text_grads(cfg, sd, tokens, x, wlog):
+    p = {k: v.clone().float() for k, v in sd.items()}
+    p["prompt_learner.ctx"].requires_grad_()
+    p["logit_scale"].requires_grad_()
+    o = Oracle(cfg, p, tokens)
+    with torch.no_grad():
+        vf, _ = o.vision(x.float())
+        vf = vf / vf.norm(dim=-1, keepdim=True)
+    tf = o.text(o.prompts())
+    tf = tf / tf.norm(dim=-1, keepdim=True)
+    logits = p["logit_scale"].exp() * vf @ tf.t()
+    (logits * wlog).sum().backward()
+    return logits.detach(), p["prompt_learner.ctx"].grad, p["logit_scale"].grad
+
+
+@pytest.mark.parametrize("cfg,B", [(TINY, 2), (VIT_B16_T8, 1)])
+def test_text_prompt_gradients_match_oracle_autograd(cfg, B):
+    """loss.backward() through VitaCLIP.forward: d ctx and d logit_scale vs the fp32 oracle under torch autograd."""
+    sd = synth_torch_state(cfg, 3)
+    m = VitaCLIP(**model_kwargs(cfg, CLASSES_3))
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size))
+    wlog = torch.randn(B, 3, generator=torch.Generator().manual_seed(11))
+    tokens = torch.cat(m.tokenized_prompts).cpu()
+    ref_logits, ref_dctx, ref_dls = _oracle_text_grads(cfg, sd, tokens, x, wlog)
+    logits, lmt, lvm = m(x.cuda())
+    assert logits.requires_grad and lmt is None and lvm is None
+    (logits * wlog.cuda()).sum().backward()
+    assert (logits.detach().cpu() - ref_logits).abs().max() <= 1e-3 * ref_logits.abs().max()
+    g = m.prompt_learner.ctx.grad
+    assert g is not None and g.shape == ref_dctx.shape and bool(torch.isfinite(g).all())
+    assert rel(g.cpu(), ref_dctx) <= 3e-2, rel(g.cpu(), ref_dctx)
+    assert abs(float(m.logit_scale.grad) - float(ref_dls)) <= 2e-3 * abs(float(ref_dls)) + 1e-6
+    # frozen parameters stay without gradient, as in the reference (VitaCLIP_model.py:230-239)
+    assert m.textual.ln_final.weight.grad is None
+    # an optimizer step on ctx must not trigger a re-pack of the frozen weights and must change the output
+    key = m._pack_key()
+    with torch.no_grad():
+        m.prompt_learner.ctx -= 0.1 * g
+    assert m._pack_key() == key
+    with torch.no_grad():
+        l2 = m(x.cuda())[0]
+    assert not torch.equal(l2, logits.detach())
