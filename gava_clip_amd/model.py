@@ -532,7 +532,9 @@ class VitaCLIP(nn.Module):
         if self.use_text_prompt_learning:
             if desc_wise:
                 assert self.training == False
-            key = self._pack_key() if (self.cache_text_features and not self.training) else None
+            # the cached text features depend on the packed weights AND on the (pass-through) context vectors
+            key = ((self._pack_key(), self.prompt_learner.ctx._version, self.prompt_learner.ctx.data_ptr())
+                   if (self.cache_text_features and not self.training) else None)
             train_text = torch.is_grad_enabled() and self.prompt_learner.ctx.requires_grad
             if train_text:
                 # differentiable text tower (gava_clip_amd/training.py): HIP kernels in both directions
