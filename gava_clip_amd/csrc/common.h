@@ -33,6 +33,10 @@ struct PrecF16 {
   static __device__ __forceinline__ unsigned cvt2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, f16x2_t));
   }
+  // c + a.lo*b.lo + a.hi*b.hi on packed pairs (v_dot2c_f32_f16), fp32 accumulate
+  static __device__ __forceinline__ float dot2(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b), c, false);
+  }
 };
 struct PrecBF16 {
   typedef __bf16 T;
@@ -48,6 +52,9 @@ struct PrecBF16 {
   }
   static __device__ __forceinline__ unsigned cvt2(float a, float b) {   // v_cvt_pk_bf16_f32
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+  }
+  static __device__ __forceinline__ float dot2(unsigned a, unsigned b, float c) {   // v_dot2c_f32_bf16
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
   }
 };
 

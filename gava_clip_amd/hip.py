@@ -97,7 +97,10 @@ class AttentionBwdArgs(C.Structure):
     _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("ld_qkv", C.c_int64), ("dout", _vp), ("ld_dout", C.c_int64),
                 ("dq", _vp), ("dk", _vp), ("dv", _vp), ("ld_dqkv", C.c_int64),
                 ("batch", C.c_int), ("heads", C.c_int), ("n", C.c_int), ("causal", C.c_int), ("prec", C.c_int),
-                ("q_scale", C.c_float)]
+                ("q_scale", C.c_float),
+                ("side_k", _vp), ("side_v", _vp), ("ld_side", C.c_int64),
+                ("dside_k", _fp), ("dside_v", _fp), ("ld_dside", C.c_int64),
+                ("n_g", C.c_int), ("T", C.c_int), ("has_summary", C.c_int), ("n_q", C.c_int)]
 
 
 _lib = None
@@ -261,8 +264,14 @@ def qgelu_backward(pre, dh, dpre, prec):
     check(load().gava_qgelu_backward(ptr(pre), ptr(dh), ptr(dpre), pre.numel(), prec, stream_ptr()), "gava_qgelu_backward")
 
 
-def attention_backward(q, k, v, dout, dq, dk, dv, *, batch, heads, n, prec, causal=False, q_scale=1.0):
+def attention_backward(q, k, v, dout, dq, dk, dv, *, batch, heads, n, prec, causal=False, q_scale=1.0,
+                       side_k=None, side_v=None, dside_k=None, dside_v=None, n_g=0, T=0, has_summary=False, n_q=0):
     a = AttentionBwdArgs()
+    a.side_k, a.side_v = ptr(side_k), ptr(side_v)
+    a.ld_side = side_k.stride(0) if side_k is not None else 0
+    a.dside_k, a.dside_v = ptr(dside_k), ptr(dside_v)
+    a.ld_dside = dside_k.stride(0) if dside_k is not None else 0
+    a.n_g, a.T, a.has_summary, a.n_q = n_g, T, int(has_summary), n_q
     a.q, a.k, a.v, a.ld_qkv = ptr(q), ptr(k), ptr(v), q.stride(0)
     a.dout, a.ld_dout = ptr(dout), dout.stride(0)
     a.dq, a.dk, a.dv, a.ld_dqkv = ptr(dq), ptr(dk), ptr(dv), dq.stride(0)

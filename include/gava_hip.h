@@ -213,15 +213,23 @@ int gava_layernorm_backward(const gava_layernorm_bwd_args* a, gava_stream_t stre
 /* QuickGELU backward: dpre = dh * s*(1 + 1.702*pre*(1-s)), s = sigmoid(1.702*pre); h16 in/out, n % 4 == 0. */
 int gava_qgelu_backward(const void* pre, const void* dh, void* dpre, size_t n, int prec, gava_stream_t stream);
 
-/* Softmax-attention backward for short sequences (n <= 88: the text tower, nn.MultiheadAttention at
- * VitaCLIP_text_encoder.py:71,83).  q (already scaled by 1/sqrt(dh)), k, v, dout: h16 rows [batch*n][ld], head h at
- * columns [64h, 64h+64).  Writes dq (times q_scale, the factor folded into q), dk, dv. */
+/* Softmax-attention backward.  q (already scaled by 1/sqrt(dh)), k, v, dout: h16 rows [batch*n][ld], head h at columns
+ * [64h, 64h+64); writes dq (times q_scale, the factor folded into q), dk, dv as h16 rows [batch*n][ld_dqkv].
+ *   - short sequences (side_k == NULL, n <= 88: the text tower, nn.MultiheadAttention at text_encoder.py:71,83, and
+ *     the T-token summary attention, vision_encoder_utils.py:169-170), optionally causal;
+ *   - vision blocks (vision_encoder_utils.py:190-191): keys = the n rows of the frame + the gathered prompt rows
+ *     [n_g global | T local rows of the clip | the frame's summary row] of side_k/side_v (same layout as
+ *     gava_attention); n + prompts <= 256.  Prompt-row gradients are ADDED (fp32 atomics) into dside_k / dside_v,
+ *     rows as side_k; the caller zeroes them.  n_q != 0: only the first n_q rows of each frame are queries. */
 typedef struct {
   const void* q; const void* k; const void* v; int64_t ld_qkv;
   const void* dout; int64_t ld_dout;
   void* dq; void* dk; void* dv; int64_t ld_dqkv;
   int batch, heads, n, causal, prec;
   float q_scale;
+  const void* side_k; const void* side_v; int64_t ld_side;
+  float* dside_k; float* dside_v; int64_t ld_dside;
+  int n_g, T, has_summary, n_q;
 } gava_attention_bwd_args;
 int gava_attention_backward(const gava_attention_bwd_args* a, gava_stream_t stream);
 

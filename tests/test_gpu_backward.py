@@ -136,3 +136,48 @@ def test_text_prompt_gradients_match_oracle_autograd(cfg, B):
     with torch.no_grad():
         l2 = m(x.cuda())[0]
     assert not torch.equal(l2, logits.detach())
+
+
+@pytest.mark.parametrize("BT,T,heads,n,G,n_q", [(16, 8, 12, 197, 8, 0), (8, 4, 2, 17, 4, 0), (4, 2, 3, 33, 0, 0), (8, 8, 2, 50, 8, 1)])
+def test_attention_backward_vision_with_prompt_rows_matches_autograd(BT, T, heads, n, G, n_q):
+    """Vision block attention (vision_encoder_utils.py:176-191): keys = the frame's n rows + G global prompt rows +
+    the T local-prompt rows of its clip + its summary row.  dq/dk/dv of the frame rows and the ACCUMULATED gradients of
+    the shared prompt rows against torch autograd on the same bf16-rounded operands."""
+    g = torch.Generator().manual_seed(BT * 31 + n)
+    D = heads * 64
+    qkv = torch.randn(BT * n, 3 * D, generator=g).bfloat16()
+    side = torch.randn(G + 2 * BT, 2 * D, generator=g).bfloat16()
+    nq = n_q or n
+    do = torch.randn(BT * n, D, generator=g).bfloat16()
+    q32 = qkv[:, :D].float().requires_grad_()
+    k32 = qkv[:, D:2 * D].float().requires_grad_()
+    v32 = qkv[:, 2 * D:].float().requires_grad_()
+    s32 = side.float().requires_grad_()
+    outs = []
+    for f in range(BT):
+        rows = slice(f * n, (f + 1) * n)
+        clip = f // T
+        srow = torch.cat([torch.arange(G), G + clip * T + torch.arange(T), torch.tensor([G + BT + f])])
+        K = torch.cat([k32[rows], s32[srow, :D]]).view(-1, heads, 64).transpose(0, 1)
+        V = torch.cat([v32[rows], s32[srow, D:]]).view(-1, heads, 64).transpose(0, 1)
+        Q = q32[rows][:nq].view(nq, heads, 64).transpose(0, 1) * 0.125
+        o = (Q @ K.transpose(-1, -2)).softmax(-1) @ V
+        outs.append(o.transpose(0, 1).reshape(nq, D))
+    dout = do.float().view(BT, n, D)[:, :nq]
+    (torch.stack(outs) * dout).sum().backward()
+    qs = qkv.float().clone(); qs[:, :D] *= 0.125
+    qd, sd_ = qs.bfloat16().cuda(), side.cuda()
+    dqkv = torch.zeros(BT * n, 3 * D, dtype=torch.bfloat16, device="cuda")
+    dside = torch.zeros(G + 2 * BT, 2 * D, dtype=torch.float32, device="cuda")
+    hip.attention_backward(qd[:, :D], qd[:, D:2 * D], qd[:, 2 * D:], do.cuda(), dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                           batch=BT, heads=heads, n=n, prec=BF, q_scale=0.125,
+                           side_k=sd_[:, :D], side_v=sd_[:, D:], dside_k=dside[:, :D], dside_v=dside[:, D:],
+                           n_g=G, T=T, has_summary=True, n_q=n_q)
+    tol = 2 ** -8 * 1.05
+    ref_q = q32.grad.view(BT, n, D)[:, :nq]
+    got_q = dqkv[:, :D].float().cpu().view(BT, n, D)[:, :nq]
+    assert (got_q - ref_q).abs().max() <= tol * ref_q.abs().max() + 1e-6
+    for name, got, ref in (("dk", dqkv[:, D:2 * D].float().cpu(), k32.grad), ("dv", dqkv[:, 2 * D:].float().cpu(), v32.grad)):
+        assert (got - ref).abs().max() <= tol * ref.abs().max() + 1e-6, name
+    # prompt rows: fp32 accumulation over every frame/head that reads them (no 16-bit rounding of the result)
+    assert (dside.cpu() - s32.grad).abs().max() <= 2e-3 * s32.grad.abs().max(), "dside"
