@@ -127,6 +127,12 @@ extern "C" size_t gava_vision_workspace_bytes(const gava_vision_model* m) {
 
 extern "C" int gava_vision_forward(const gava_vision_model* m, const float* x, float* cls_x, float* summary,
                                    float* debug_cls, void* workspace, size_t workspace_bytes, gava_stream_t stream) {
+  return gava_vision_forward_train(m, x, cls_x, summary, debug_cls, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float* x, float* cls_x, float* summary,
+                                         float* debug_cls, float* saved_x, void* workspace, size_t workspace_bytes,
+                                         gava_stream_t stream) {
   TRY(check_vision(m));
   if (!x || !cls_x || !summary || !workspace) return GAVA_EINVAL;
   const VisionWs w = carve_vision(m, workspace, workspace_bytes);
@@ -150,11 +156,19 @@ extern "C" int gava_vision_forward(const gava_vision_model* m, const float* x, f
     TRY(gava_gemm(&a, stream));
   }
   TRY(gava::cls_embed(w.X, m->cls_token, m->pos_embed, m->time_embed, BT, m->T_in, D, fs, s));
+  // training: slot 0 = the embedding before ln_pre, slot 1+i = the input of block i, slot layers+1 = the final stream
+  auto keep = [&](int slot) -> int {
+    if (!saved_x) return GAVA_OK;
+    return hipMemcpyAsync(saved_x + (size_t)slot * R * D, w.X, (size_t)R * D * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess
+               ? GAVA_OK : GAVA_ELAUNCH;
+  };
+  TRY(keep(0));
   TRY(ln(w.X, D, nullptr, m->lnpre_g, m->lnpre_b, nullptr, 0, w.X, D, R, D, pr, stream));
 
   // ---- blocks (VitaCLIP_vision_encoder.py:115-121, VitaCLIP_vision_encoder_utils.py:155-203)
   for (int i = 0; i < m->layers; ++i) {
     const gava_vision_layer& L = m->layer[i];
+    TRY(keep(1 + i));
     const unsigned short* wqkv = (const unsigned short*)L.w_qkv;
     // prompt ("side") path: cls_proj, summary token, local prompts -> K/V-only rows.  The main path does not
     // need it before attention, so it runs on the side stream next to LN1 + the QKV GEMM.
@@ -229,6 +243,7 @@ extern "C" int gava_vision_forward(const gava_vision_model* m, const float* x, f
     if (debug_cls) TRY(gava::copy_rows(w.X, fs, debug_cls + (long)i * BT * D, BT, D, s));
   }
 
+  TRY(keep(1 + m->layers));
   // ---- head (VitaCLIP_vision_encoder.py:126-130)
   // split precision (3 MFMA passes): M = BT rows only, and its rounding lands directly on the output
   TRY(ln(w.X, fs, nullptr, m->lnpost_g, m->lnpost_b, w.CLSPOST, 3 * D, nullptr, 0, BT, D, pr, stream, 1));

@@ -20,7 +20,7 @@ EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_vision_workspace_bytes", "gava_vision_forward", "gava_text_workspace_bytes",
            "gava_text_forward", "gava_similarity_head", "gava_convert_h16", "gava_debug_set_buffer",
            "gava_preprocess_clip", "gava_layernorm_backward", "gava_qgelu_backward", "gava_attention_backward",
-           "gava_text_forward_train"]
+           "gava_text_forward_train", "gava_vision_forward_train"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 
@@ -149,6 +149,8 @@ def load():
     lib.gava_qgelu_backward.restype = C.c_int
     lib.gava_attention_backward.argtypes = [C.POINTER(AttentionBwdArgs), _vp]
     lib.gava_attention_backward.restype = C.c_int
+    lib.gava_vision_forward_train.argtypes = [C.POINTER(VisionModel), _fp, _fp, _fp, _fp, _fp, _vp, C.c_size_t, _vp]
+    lib.gava_vision_forward_train.restype = C.c_int
     lib.gava_text_forward_train.argtypes = [C.POINTER(TextModel), _ip, _fp, _ip, _fp, _fp, _vp, C.c_size_t, _vp]
     lib.gava_text_forward_train.restype = C.c_int
     _lib = lib

@@ -346,6 +346,13 @@ class VitaCLIP(nn.Module):
         ps = next(self.parameters())
         return (self.prec, self.text_split_precision, ps.device, addr, ver)
 
+    def _pack_vision_backward(self):
+        from . import training
+        key = self._pack_key()
+        if getattr(self, "_bwd_pack_v", None) is None or self._bwd_pack_v[0] != key:
+            self._bwd_pack_v = (key, training.pack_vision_backward(self))
+        return self._bwd_pack_v[1]
+
     def _pack_text_backward(self):
         from . import training
         key = self._pack_key()
@@ -431,8 +438,9 @@ class VitaCLIP(nn.Module):
         return ws
 
     # ---- encoders -----------------------------------------------------------------------------
-    def encode_video(self, x):
-        """CLIPVisionEncoder.forward on the HIP path -> (cls_x (B,E), summary (B,D)), fp32."""
+    def encode_video(self, x, saved=None):
+        """CLIPVisionEncoder.forward on the HIP path -> (cls_x (B,E), summary (B,D)), fp32.
+        saved: optional fp32 [layers+2, B*T*(n+1), D] that receives what the backward recomputes from."""
         if not x.is_cuda:
             raise hip.GavaError("VitaCLIP (gava_clip_amd) runs on the HIP device only: move the model and the "
                                 "input with .cuda(); there is no CPU fallback")
@@ -461,8 +469,9 @@ class VitaCLIP(nn.Module):
         cls_x = torch.empty(B, sh["E"], dtype=torch.float32, device=x.device)
         summary = torch.empty(B * T // self.num_frames, sh["D"], dtype=torch.float32, device=x.device)
         dbg = torch.empty(sh["layers"], B * T, sh["D"], dtype=torch.float32, device=x.device) if self.debug_taps else None
-        hip.check(lib.gava_vision_forward(C.byref(m), hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), hip.ptr(dbg),
-                                          hip.ptr(ws), ws.numel(), hip.stream_ptr()), "gava_vision_forward")
+        hip.check(lib.gava_vision_forward_train(C.byref(m), hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), hip.ptr(dbg),
+                                                hip.ptr(saved), hip.ptr(ws), ws.numel(), hip.stream_ptr()),
+                  "gava_vision_forward")
         self.last["cls_rows"] = dbg
         return cls_x, summary
 
@@ -505,6 +514,10 @@ class VitaCLIP(nn.Module):
         out = torch.empty(dist.get_world_size() * feats.shape[0], feats.shape[1], dtype=feats.dtype, device=feats.device)
         dist.all_gather_into_tensor(out, feats)
         return out
+
+    def _vision_trainables(self):
+        from .training import _vision_trainables
+        return _vision_trainables(self)
 
     def _train_head(self, video, text, summary, desc_wise):
         """Similarity head under autograd (VitaCLIP_model.py:248,255,287-293,308-309): 2*B*C*E flop on (B,E)/(C,E)
@@ -558,12 +571,21 @@ class VitaCLIP(nn.Module):
                 self._text_cache = (key, text) if key is not None else None
         else:
             text = self.text_features.to(device=x.device, dtype=torch.float32).contiguous()
-        cls_x, summary = self.encode_video(x)
+        train_vision = torch.is_grad_enabled() and any(p.requires_grad for _, p in self._vision_trainables())
+        if train_vision:
+            # differentiable vision tower (gava_clip_amd/training.py): gradients of the prompt parameters
+            from .training import VisionTowerFn
+            if T != self.num_frames:
+                raise NotImplementedError("training needs T == num_frames (time_embed is resized otherwise)")
+            cls_x, summary = VisionTowerFn.apply(self, x, *[p for _, p in self._vision_trainables()])
+        else:
+            cls_x, summary = self.encode_video(x)
         if text_stream is not None:
             torch.cuda.current_stream(x.device).wait_stream(text_stream)
             text.record_stream(torch.cuda.current_stream(x.device))
-        video = self._gather(cls_x)
-        if torch.is_grad_enabled() and (text.requires_grad or self.logit_scale.requires_grad):
+        # under autograd every rank keeps its own clips (the reference's DDP computes the loss on local logits)
+        video = cls_x if cls_x.requires_grad else self._gather(cls_x)
+        if torch.is_grad_enabled() and (text.requires_grad or video.requires_grad or self.logit_scale.requires_grad):
             if (self.add_nte and video_nte is not None) or (self.use_support_memory and memory is not None):
                 raise NotImplementedError("auxiliary heads under autograd (SURVEY §8f row 4)")
             return self._train_head(video, text, summary, desc_wise)

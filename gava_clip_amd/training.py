@@ -135,3 +135,204 @@ class TextTowerFn(torch.autograd.Function):
         (saved,) = fctx.saved_tensors
         dctx = text_backward(fctx.model, saved, dtext)
         return None, dctx.to(dtext.dtype)
+
+
+# =================================================================================================
+# Vision tower (second stage): gradients of the Vita-CLIP prompt parameters through the frozen ViT
+# =================================================================================================
+# Trainable on the vision side (VitaCLIP_model.py:230-234: names containing summary / local / global / time_embed):
+#   visual.global_prompts (layers,G,D), blocks.i.local_prompts (1,T,D), blocks.i.summary_ln.{weight,bias},
+#   blocks.i.summary_attn_layer.{q,k,v,out}_proj.{weight,bias}, visual.time_embed (T,D).
+# Chain (VitaCLIP_vision_encoder.py:102-132, VitaCLIP_vision_encoder_utils.py:155-203), in reverse:
+#   d cls_x -> mean over T -> proj^T -> ln_post' (CLS rows) -> 12 x block' -> ln_pre' -> sum over tokens = d time_embed
+#   block': MLP' and attention' on all B*T*197 rows (dgrad GEMMs + qgelu' + LayerNorm' + gava_attention_backward);
+#   the attention' also yields the gradient of the shared prompt K/V rows -> K/V projection^T -> norm1' ->
+#   d global_prompts, d local_prompts, and through the summary path (T-token attention, summary_ln, cls_proj) both the
+#   parameter gradients of summary_ln / summary_attn_layer (wgrad = gava_gemm on transposed operands) and a
+#   contribution to the CLS rows of dX.
+# Activations are recomputed per block from its saved fp32 input (the forward kernels, bf16 operands).
+
+def _vision_trainables(model):
+    """Ordered (name, parameter) list of the vision-side parameters the reference leaves trainable."""
+    return [(n, p) for n, p in model.visual.named_parameters()
+            if ("summary" in n or "local" in n or "global" in n or "time_embed" in n)]
+
+
+def pack_vision_backward(model):
+    v = model.visual
+    f32 = lambda p: p.detach().float().contiguous()
+    layers = []
+    for blk in v.blocks:
+        a, s = blk.attn, blk.summary_attn_layer
+        wqkv = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).detach()
+        wsqkv = torch.cat([s.q_proj.weight, s.k_proj.weight, s.v_proj.weight], 0).detach()
+        D = wqkv.shape[1]
+        layers.append(dict(
+            w_qkv=_bf16(wqkv), w_qkv_t=_bf16(wqkv.t()), b_qkv=f32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)),
+            w_kv=_bf16(wqkv[D:]), w_kv_t=_bf16(wqkv[D:].t()),
+            w_out=_bf16(a.out_proj.weight), w_out_t=_bf16(a.out_proj.weight.detach().t()), b_out=f32(a.out_proj.bias),
+            w_fc1=_bf16(blk.mlp.fc1.weight), w_fc1_t=_bf16(blk.mlp.fc1.weight.detach().t()), b_fc1=f32(blk.mlp.fc1.bias),
+            w_fc2_t=_bf16(blk.mlp.fc2.weight.detach().t()),
+            w_cls=_bf16(blk.cls_proj.weight), w_cls_t=_bf16(blk.cls_proj.weight.detach().t()), b_cls=f32(blk.cls_proj.bias),
+            w_sqkv=_bf16(wsqkv), w_sqkv_t=_bf16(wsqkv.t()),
+            w_sout=_bf16(s.out_proj.weight), w_sout_t=_bf16(s.out_proj.weight.detach().t())))
+    return dict(layers=layers, proj=_bf16(v.proj))    # cls_x = ln_post(x) @ proj (D,E): dx = d @ proj^T = gemm(d, W=proj)
+
+
+def _pad_k(t, mult=64):
+    """[N][K] -> K padded with zero columns to a multiple of `mult` (GEMM reduction-dim granularity)."""
+    k = t.shape[1]
+    kp = (k + mult - 1) // mult * mult
+    return t.contiguous() if kp == k else torch.nn.functional.pad(t, (0, kp - k)).contiguous()
+
+
+def _wgrad(dy16, x16):
+    """dW[o][i] = sum_m dy[m][o] * x[m][i] for an nn.Linear weight [out][in]: gava_gemm on the transposed operands."""
+    A, W = _pad_k(dy16.t()), _pad_k(x16.t())
+    out = torch.empty(A.shape[0], W.shape[0], dtype=torch.float32, device=dy16.device)
+    hip.gemm(A, W, None, out, epilogue=hip.EPI_F32, prec=BWD)
+    return out
+
+
+def vision_backward(model, saved, dcls_x, B, T):
+    """d cls_x (B,E) -> {parameter name: gradient} for the trainable vision parameters."""
+    sh = model._shape
+    bw = model._pack_vision_backward()
+    D, H, F, E, G, NL = sh["D"], sh["H"], sh["F"], sh["E"], sh["G"], sh["layers"]
+    n1 = (sh["size"] // sh["P"]) ** 2 + 1
+    BT, R, SR = B * T, B * T * n1, G + 2 * B * T
+    dev = dcls_x.device
+    bf = torch.bfloat16
+    new = lambda *s, dtype=bf: torch.empty(*s, dtype=dtype, device=dev)
+    conv = lambda src, dst: hip.check(hip.load().gava_convert_h16(hip.ptr(src), hip.ptr(dst), src.numel(), BWD, hip.stream_ptr()), "convert")
+    v = model.visual
+    grads = {}
+    cls_idx = (torch.arange(BT, device=dev, dtype=torch.int32) * n1).contiguous()
+
+    # ---- head: cls_x = mean_t(ln_post(x_cls) @ proj)                          (VitaCLIP_vision_encoder.py:126-128)
+    dproj = (dcls_x.float() / T).unsqueeze(1).expand(B, T, E).reshape(BT, E).contiguous()
+    dclspost = new(BT, D, dtype=torch.float32)
+    hip.gemm(hip.convert_h16(dproj, BWD), bw["proj"], None, dclspost, epilogue=hip.EPI_F32, prec=BWD)
+    dX = torch.zeros(R, D, dtype=torch.float32, device=dev)
+    hip.layernorm_backward(saved[NL + 1], v.ln_post.weight.detach().float().contiguous(), dclspost, dX,
+                           x_row_index=cls_idx, dx_row_index=cls_idx, rows=BT)
+
+    xn, qkv, mix, pre = new(R, D), new(R, 3 * D), new(R, D), new(R, F)
+    X1, dx16, dhid, dmix, dqkv = new(R, D, dtype=torch.float32), new(R, D), new(R, F), new(R, D), new(R, 3 * D)
+    dxn = new(R, D, dtype=torch.float32)
+    dgp = torch.zeros_like(v.global_prompts, dtype=torch.float32)
+    for i in reversed(range(NL)):
+        P, blk, X0 = bw["layers"][i], v.blocks[i], saved[1 + i]
+        f32 = lambda p: p.detach().float().contiguous()
+        ln1_g, ln1_b, ln2_g, ln2_b = f32(blk.norm1.weight), f32(blk.norm1.bias), f32(blk.norm2.weight), f32(blk.norm2.bias)
+        sln_g, sln_b = f32(blk.summary_ln.weight), f32(blk.summary_ln.bias)
+        s = blk.summary_attn_layer
+        b_sqkv = f32(torch.cat([s.q_proj.bias, s.k_proj.bias, s.v_proj.bias], 0))
+        # ---- recompute: prompt ("side") path                                 (vision_encoder_utils.py:164-190)
+        cls16 = hip.convert_h16(X0.view(BT, n1, D)[:, 0].contiguous(), BWD)
+        CP = new(BT, D, dtype=torch.float32)
+        hip.gemm(cls16, P["w_cls"], P["b_cls"], CP, epilogue=hip.EPI_F32, prec=BWD)
+        CPn = new(BT, D)
+        hip.layernorm(CP, sln_g, sln_b, out16=CPn, prec=BWD)
+        SQKV = new(BT, 3 * D)
+        hip.gemm(CPn, P["w_sqkv"], b_sqkv, SQKV, epilogue=hip.EPI_H16, prec=BWD, scale_cols=D, scale=0.125)
+        SMIX = new(BT, D)
+        hip.attention(SQKV[:, :D], SQKV[:, D:2 * D], SQKV[:, 2 * D:], SMIX, batch=BT // T, heads=H, n_q=T, n_kmain=T, prec=BWD)
+        SUMM = new(BT, D, dtype=torch.float32)
+        hip.gemm(SMIX, P["w_sout"], f32(s.out_proj.bias), SUMM, epilogue=hip.EPI_F32, prec=BWD, resid=CP)
+        lp = blk.local_prompts.detach().float()[0]                                     # (T, D)
+        SIDE = torch.cat([v.global_prompts.detach().float()[i], (CP.view(B, T, D) + lp).view(BT, D), SUMM], 0).contiguous()
+        SIDEn = new(SR, D)
+        hip.layernorm(SIDE, ln1_g, ln1_b, out16=SIDEn, prec=BWD)
+        SIDEKV = new(SR, 2 * D)
+        hip.gemm(SIDEn, P["w_kv"], P["b_qkv"][D:], SIDEKV, epilogue=hip.EPI_H16, prec=BWD)
+        # ---- recompute: main rows
+        hip.layernorm(X0, ln1_g, ln1_b, out16=xn, prec=BWD)
+        hip.gemm(xn, P["w_qkv"], P["b_qkv"], qkv, epilogue=hip.EPI_H16, prec=BWD, scale_cols=D, scale=0.125)
+        hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], mix, batch=BT, heads=H, n_q=n1, n_kmain=n1, prec=BWD,
+                      side_k=SIDEKV[:, :D], side_v=SIDEKV[:, D:], n_g=G, T=T, has_summary=True)
+        hip.gemm(mix, P["w_out"], P["b_out"], X1, epilogue=hip.EPI_F32, prec=BWD, resid=X0)
+        hip.layernorm(X1, ln2_g, ln2_b, out16=xn, prec=BWD)
+        hip.gemm(xn, P["w_fc1"], P["b_fc1"], pre, epilogue=hip.EPI_H16, prec=BWD)
+        # ---- MLP'                                                           (vision_encoder_utils.py:109-115,199)
+        conv(dX, dx16)
+        hip.gemm(dx16, P["w_fc2_t"], None, dhid, epilogue=hip.EPI_H16, prec=BWD)
+        hip.qgelu_backward(pre, dhid, dhid, BWD)
+        hip.gemm(dhid, P["w_fc1_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)
+        hip.layernorm_backward(X1, ln2_g, dxn, dX, accumulate=True)
+        # ---- attention'                                                     (vision_encoder_utils.py:61-81,190-191)
+        conv(dX, dx16)
+        hip.gemm(dx16, P["w_out_t"], None, dmix, epilogue=hip.EPI_H16, prec=BWD)
+        dside = torch.zeros(SR, 2 * D, dtype=torch.float32, device=dev)
+        hip.attention_backward(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dmix, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                               batch=BT, heads=H, n=n1, prec=BWD, q_scale=0.125,
+                               side_k=SIDEKV[:, :D], side_v=SIDEKV[:, D:], dside_k=dside[:, :D], dside_v=dside[:, D:],
+                               n_g=G, T=T, has_summary=True)
+        hip.gemm(dqkv, P["w_qkv_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)
+        hip.layernorm_backward(X0, ln1_g, dxn, dX, accumulate=True)
+        # ---- prompt rows': K/V projection^T, norm1', split into global / local / summary
+        dSIDEn = new(SR, D, dtype=torch.float32)
+        hip.gemm(hip.convert_h16(dside, BWD), P["w_kv_t"], None, dSIDEn, epilogue=hip.EPI_F32, prec=BWD)
+        dSIDE = new(SR, D, dtype=torch.float32)
+        hip.layernorm_backward(SIDE, ln1_g, dSIDEn, dSIDE)
+        dgp[i] = dSIDE[:G]
+        dlocal, dSUMM = dSIDE[G:G + BT], dSIDE[G + BT:]
+        grads[f"blocks.{i}.local_prompts"] = dlocal.view(B, T, D).sum(0).unsqueeze(0)
+        dCP = (dlocal + dSUMM).contiguous()                      # local = lp + CP;  SUMM = CP + out_proj(...)
+        # ---- summary attention' (T tokens per clip) with parameter gradients
+        dSUMM16 = hip.convert_h16(dSUMM.contiguous(), BWD)
+        dSMIX = new(BT, D)
+        hip.gemm(dSUMM16, P["w_sout_t"], None, dSMIX, epilogue=hip.EPI_H16, prec=BWD)
+        grads[f"blocks.{i}.summary_attn_layer.out_proj.weight"] = _wgrad(dSUMM16, SMIX)
+        grads[f"blocks.{i}.summary_attn_layer.out_proj.bias"] = dSUMM.sum(0)
+        dSQKV = new(BT, 3 * D)
+        hip.attention_backward(SQKV[:, :D], SQKV[:, D:2 * D], SQKV[:, 2 * D:], dSMIX, dSQKV[:, :D], dSQKV[:, D:2 * D], dSQKV[:, 2 * D:],
+                               batch=BT // T, heads=H, n=T, prec=BWD, q_scale=0.125)
+        dWs = _wgrad(dSQKV, CPn)
+        dbs = dSQKV.float().sum(0)
+        for k, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+            grads[f"blocks.{i}.summary_attn_layer.{nm}.weight"] = dWs[k * D:(k + 1) * D]
+            grads[f"blocks.{i}.summary_attn_layer.{nm}.bias"] = dbs[k * D:(k + 1) * D]
+        dCPn = new(BT, D, dtype=torch.float32)
+        hip.gemm(dSQKV, P["w_sqkv_t"], None, dCPn, epilogue=hip.EPI_F32, prec=BWD)
+        dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        hip.layernorm_backward(CP, sln_g, dCPn, dCP, accumulate=True, dgamma=dg, dbeta=db)
+        grads[f"blocks.{i}.summary_ln.weight"], grads[f"blocks.{i}.summary_ln.bias"] = dg, db
+        # ---- cls_proj' (frozen weight): back onto the CLS rows of the block input
+        dCLS = new(BT, D, dtype=torch.float32)
+        hip.gemm(hip.convert_h16(dCP, BWD), P["w_cls_t"], None, dCLS, epilogue=hip.EPI_F32, prec=BWD)
+        dX.view(BT, n1, D)[:, 0] += dCLS
+    grads["global_prompts"] = dgp
+    # ---- ln_pre' and the temporal embedding (VitaCLIP_vision_encoder.py:86-100,108-113): time_embed[t] is added to
+    #      every token of frame t
+    hip.layernorm_backward(saved[0], v.ln_pre.weight.detach().float().contiguous(), dX, dX)
+    grads["time_embed"] = dX.view(B, T, n1, D).sum(dim=(0, 2))
+    return grads
+
+
+class VisionTowerFn(torch.autograd.Function):
+    """cls_x = f(x; prompt parameters) with the HIP vision tower in both directions.  `params` are the trainable vision
+    parameters in `_vision_trainables` order (they enter only so that autograd routes their gradients)."""
+
+    @staticmethod
+    def forward(fctx, model, x, *params):
+        sh = model._shape
+        B, _, T = x.shape[:3]
+        n1 = (sh["size"] // sh["P"]) ** 2 + 1
+        saved = torch.empty(sh["layers"] + 2, B * T * n1, sh["D"], dtype=torch.float32, device=x.device)
+        cls_x, summary = model.encode_video(x, saved=saved)
+        fctx.model, fctx.BT = model, (B, T)
+        fctx.save_for_backward(saved)
+        fctx.mark_non_differentiable(summary)
+        return cls_x, summary
+
+    @staticmethod
+    def backward(fctx, dcls_x, _dsummary):
+        (saved,) = fctx.saved_tensors
+        model = fctx.model
+        g = vision_backward(model, saved, dcls_x.contiguous(), *fctx.BT)
+        out = []
+        for name, p in _vision_trainables(model):
+            gi = g.get(name)
+            out.append(gi.reshape(p.shape).to(p.dtype) if (gi is not None and p.requires_grad) else None)
+        return (None, None, *out)

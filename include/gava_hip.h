@@ -239,6 +239,12 @@ int gava_text_forward_train(const gava_text_model* m, const int32_t* tokens, con
                             const int32_t* eot_index, float* out, float* saved_x, void* workspace,
                             size_t workspace_bytes, gava_stream_t stream);
 
+/* gava_vision_forward that also keeps what the backward recomputes from: saved_x fp32 [layers+2][B*T_in*(n+1)][D] =
+ * the embedding before ln_pre, the input of every block, and the final residual stream. */
+int gava_vision_forward_train(const gava_vision_model* m, const float* x, float* cls_x, float* summary,
+                              float* debug_cls, float* saved_x, void* workspace, size_t workspace_bytes,
+                              gava_stream_t stream);
+
 /* Clip preprocessing of the evaluation data path (video_dataset/dataset.py:117-139, the
  * num_spatial_views = num_temporal_views = 1 case that every eval script uses): from the decoded RGB frames of
  * one video, uint8 [n_frames][height][width][3], to the model input slot fp32 [3][T][size][size]:

@@ -181,3 +181,56 @@ def test_attention_backward_vision_with_prompt_rows_matches_autograd(BT, T, head
         assert (got - ref).abs().max() <= tol * ref.abs().max() + 1e-6, name
     # prompt rows: fp32 accumulation over every frame/head that reads them (no 16-bit rounding of the result)
     assert (dside.cpu() - s32.grad).abs().max() <= 2e-3 * s32.grad.abs().max(), "dside"
+
+
+def _oracle_all_grads(cfg, sd, tokens, x, wlog):
+    """fp32 oracle under torch autograd: gradients of every parameter the reference trains (VitaCLIP_model.py:230-239)."""
+    p = {k: v.clone().float() for k, v in sd.items()}
+    names = [k for k in p if k == "logit_scale" or k == "prompt_learner.ctx" or
+             (k.startswith("visual.") and any(t in k for t in ("summary", "local", "global", "time_embed")))]
+    for k in names:
+        p[k].requires_grad_()
+    o = Oracle(cfg, p, tokens)
+    vf, _ = o.vision(x.float())
+    vf = vf / vf.norm(dim=-1, keepdim=True)
+    tf = o.text(o.prompts())
+    tf = tf / tf.norm(dim=-1, keepdim=True)
+    logits = p["logit_scale"].exp() * vf @ tf.t()
+    (logits * wlog).sum().backward()
+    return logits.detach(), {k: p[k].grad for k in names}
+
+
+@pytest.mark.parametrize("cfg,B", [(TINY, 2), (VIT_B16_T8, 1)])
+def test_all_trainable_gradients_match_oracle_autograd(cfg, B):
+    """loss.backward() through the whole drop-in model in train mode (training/train.py:441-490): every parameter the
+    reference trains gets the oracle's gradient (norm-wise, bf16 backward operands vs fp32 autograd), frozen ones none."""
+    sd = synth_torch_state(cfg, 3)
+    m = VitaCLIP(**model_kwargs(cfg, CLASSES_3))
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size))
+    wlog = torch.randn(B, 3, generator=torch.Generator().manual_seed(5))
+    tokens = torch.cat(m.tokenized_prompts).cpu()
+    ref_logits, ref = _oracle_all_grads(cfg, sd, tokens, x, wlog)
+    logits = m(x.cuda())[0]
+    (logits * wlog.cuda()).sum().backward()
+    assert (logits.detach().cpu() - ref_logits).abs().max() <= 1e-3 * ref_logits.abs().max()
+    got = {n: p.grad for n, p in m.named_parameters()}
+    worst = {}
+    for name, g_ref in ref.items():
+        g = got[name]
+        assert g is not None, name
+        assert g.shape == g_ref.shape and bool(torch.isfinite(g).all()), name
+        if name.endswith("k_proj.bias"):
+            # softmax is invariant to a constant added to every key: this gradient is exactly zero in exact arithmetic
+            # (the oracle returns ~1e-9 noise), so it is measured against the scale of its sibling, d q_proj.bias
+            scale = ref[name.replace("k_proj", "q_proj")].norm()
+            worst[name] = float(g.cpu().norm() / scale) * 0.1
+            assert float(g_ref.norm()) <= 1e-4 * float(scale)
+            continue
+        worst[name] = rel(g.cpu(), g_ref)
+    bad = {k: v for k, v in worst.items() if v > 4e-2}
+    assert not bad, bad
+    for n, p in m.named_parameters():
+        if n not in ref:
+            assert p.grad is None, n
