@@ -201,8 +201,8 @@ __global__ __launch_bounds__(256) void attention_bwd_small_kernel(const AttnBwdP
 //   * softmax statistics and delta = rowsum(P*dP) are wave reductions + an 8-entry LDS exchange per row;
 //   * dQ = dS K is the one product that runs across keys: dS block and K go through LDS, thread = (d, row).
 // Main-row gradients are written as h16 into a [rows][3D] buffer (the operand of the in-projection dgrad);
-// prompt-row gradients are shared by many workgroups (global prompts: every frame) and are accumulated with fp32
-// atomics into dside [G + 2*BT][2D].
+// prompt-row gradients are shared by many workgroups (global prompts: every frame): each workgroup stores its
+// partial into dside [frame][G + T + 1][2D] and the caller reduces over the frames that share a row.
 constexpr int AB_QB = 8, AB_MAXK = 256, AB_HALF = DH / 2;   // 8 query rows per block: 8 x 64 dQ outputs = one per thread
 
 struct AttnBwdMainParams {
@@ -381,10 +381,16 @@ __global__ __launch_bounds__(512) void attention_bwd_main_kernel(const AttnBwdMa
         *reinterpret_cast<uint2*>(ov + d) = pack4<P>(dvr[d], dvr[d + 1], dvr[d + 2], dvr[d + 3]);
       }
     } else {
-      float* ok = p.dsk + side_row * p.ld_dside + h * DH + d0;
-      float* ov = p.dsv + side_row * p.ld_dside + h * DH + d0;
+      // per-frame partial of a shared prompt row: plain stores, the caller sums over the frames that share the row
+      // (atomics into the shared rows cost 30x the arithmetic: 512 frames x 12 heads contend for the global prompts)
+      const long pr = (long)n * (nk - p.n_kmain) + (j - p.n_kmain);
+      float* ok = p.dsk + pr * p.ld_dside + h * DH + d0;
+      float* ov = p.dsv + pr * p.ld_dside + h * DH + d0;
 #pragma unroll
-      for (int d = 0; d < AB_HALF; ++d) { atomicAdd(ok + d, dkr[d]); atomicAdd(ov + d, dvr[d]); }
+      for (int d = 0; d < AB_HALF; d += 4) {
+        *reinterpret_cast<float4*>(ok + d) = make_float4(dkr[d], dkr[d + 1], dkr[d + 2], dkr[d + 3]);
+        *reinterpret_cast<float4*>(ov + d) = make_float4(dvr[d], dvr[d + 1], dvr[d + 2], dvr[d + 3]);
+      }
     }
   }
 }
@@ -445,7 +451,8 @@ extern "C" int gava_attention_backward(const gava_attention_bwd_args* a, gava_st
   if (a->causal) return GAVA_EINVAL;
   if (n_side && (!a->side_v || !a->dside_k || !a->dside_v || a->n_g < 0 || a->T <= 0 || a->batch % a->T)) return GAVA_EINVAL;
   if ((a->ld_qkv | a->ld_side) % 8) return GAVA_EINVAL;
-  if ((((uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->side_k | (uintptr_t)a->side_v) & 15) || (a->ld_dqkv % 4)) return GAVA_EINVAL;
+  if ((((uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->side_k | (uintptr_t)a->side_v | (uintptr_t)a->dside_k | (uintptr_t)a->dside_v) & 15) ||
+      (a->ld_dqkv % 4) || (a->ld_dside % 4)) return GAVA_EINVAL;
   AttnBwdMainParams p;
   p.q = (const unsigned short*)a->q; p.k = (const unsigned short*)a->k; p.v = (const unsigned short*)a->v; p.ld_qkv = a->ld_qkv;
   p.sk = (const unsigned short*)a->side_k; p.sv = (const unsigned short*)a->side_v; p.ld_side = a->ld_side;

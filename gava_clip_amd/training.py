@@ -263,16 +263,21 @@ def vision_backward(model, saved, dcls_x, B, T):
         # ---- attention'                                                     (vision_encoder_utils.py:61-81,190-191)
         conv(dX, dx16)
         hip.gemm(dx16, P["w_out_t"], None, dmix, epilogue=hip.EPI_H16, prec=BWD)
-        dside = torch.zeros(SR, 2 * D, dtype=torch.float32, device=dev)
+        part = new(BT, G + T + 1, 2 * D, dtype=torch.float32)     # per-frame partials of the shared prompt rows
+        dside = part.view(BT * (G + T + 1), 2 * D)
         hip.attention_backward(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dmix, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
                                batch=BT, heads=H, n=n1, prec=BWD, q_scale=0.125,
                                side_k=SIDEKV[:, :D], side_v=SIDEKV[:, D:], dside_k=dside[:, :D], dside_v=dside[:, D:],
                                n_g=G, T=T, has_summary=True)
         hip.gemm(dqkv, P["w_qkv_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)
         hip.layernorm_backward(X0, ln1_g, dxn, dX, accumulate=True)
-        # ---- prompt rows': K/V projection^T, norm1', split into global / local / summary
+        # ---- prompt rows': sum the partials over the frames that share a row (global: all; local: the T frames of the
+        #      clip; summary: its own frame), then K/V projection^T, norm1', split into global / local / summary
+        pv = part.view(B, T, G + T + 1, 2 * D)
+        dsidekv = torch.cat([pv[:, :, :G].sum(dim=(0, 1)), pv[:, :, G:G + T].sum(dim=1).reshape(BT, 2 * D),
+                             pv[:, :, G + T].reshape(BT, 2 * D)], 0).contiguous()
         dSIDEn = new(SR, D, dtype=torch.float32)
-        hip.gemm(hip.convert_h16(dside, BWD), P["w_kv_t"], None, dSIDEn, epilogue=hip.EPI_F32, prec=BWD)
+        hip.gemm(hip.convert_h16(dsidekv, BWD), P["w_kv_t"], None, dSIDEn, epilogue=hip.EPI_F32, prec=BWD)
         dSIDE = new(SR, D, dtype=torch.float32)
         hip.layernorm_backward(SIDE, ln1_g, dSIDEn, dSIDE)
         dgp[i] = dSIDE[:G]

@@ -219,8 +219,10 @@ int gava_qgelu_backward(const void* pre, const void* dh, void* dpre, size_t n, i
  *     the T-token summary attention, vision_encoder_utils.py:169-170), optionally causal;
  *   - vision blocks (vision_encoder_utils.py:190-191): keys = the n rows of the frame + the gathered prompt rows
  *     [n_g global | T local rows of the clip | the frame's summary row] of side_k/side_v (same layout as
- *     gava_attention); n + prompts <= 256.  Prompt-row gradients are ADDED (fp32 atomics) into dside_k / dside_v,
- *     rows as side_k; the caller zeroes them.  n_q != 0: only the first n_q rows of each frame are queries. */
+ *     gava_attention); n + prompts <= 256.  Prompt rows are shared between frames, so their gradients come out as
+ *     per-frame partials dside_k / dside_v fp32 [batch][n_g + T + 1][ld_dside] (plain stores; row order global,
+ *     local, summary) which the caller sums over the frames sharing a row.  n_q != 0: only the first n_q rows of
+ *     each frame are queries. */
 typedef struct {
   const void* q; const void* k; const void* v; int64_t ld_qkv;
   const void* dout; int64_t ld_dout;
