@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgava_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "rowops.hip", "forward.hip", "preprocess.hip", "backward.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "rowops.hip", "forward.hip", "preprocess.hip", "backward.hip", "attention_bwd.hip"]
 
 
 def hipcc():

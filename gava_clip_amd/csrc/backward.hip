@@ -191,210 +191,6 @@ __global__ __launch_bounds__(256) void attention_bwd_small_kernel(const AttnBwdP
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Attention backward for the vision blocks: one workgroup per (frame, head), 197 queries x 214 keys, the keys
-// being the frame's own rows plus the gathered prompt ("side") rows exactly as in attention.hip.
-// First correct version, VALU arithmetic with fp32 accumulation (an MFMA version is the next step):
-//   * a thread pair owns key j (32 head dims each): K[j], V[j] and the dK[j], dV[j] accumulators live in registers, so
-//     S = Q K^T, dP = dO V^T, dV += P^T dO and dK += dS^T Q need no cross-thread traffic at all - queries are
-//     processed in blocks of 8 rows that every thread reads as LDS broadcasts;
-//   * softmax statistics and delta = rowsum(P*dP) are wave reductions + an 8-entry LDS exchange per row;
-//   * dQ = dS K is the one product that runs across keys: dS block and K go through LDS, thread = (d, row).
-// Main-row gradients are written as h16 into a [rows][3D] buffer (the operand of the in-projection dgrad);
-// prompt-row gradients are shared by many workgroups (global prompts: every frame): each workgroup stores its
-// partial into dside [frame][G + T + 1][2D] and the caller reduces over the frames that share a row.
-constexpr int AB_QB = 8, AB_MAXK = 256, AB_HALF = DH / 2;   // 8 query rows per block: 8 x 64 dQ outputs = one per thread
-
-struct AttnBwdMainParams {
-  const unsigned short* q; const unsigned short* k; const unsigned short* v; long ld_qkv;
-  const unsigned short* sk; const unsigned short* sv; long ld_side;
-  const unsigned short* dout; long ld_dout;
-  unsigned short* dq; unsigned short* dk; unsigned short* dv; long ld_dqkv;
-  float* dsk; float* dsv; long ld_dside;
-  int batch, heads, n_q, n_kmain, n_g, T, has_summary, n_keys;
-  float q_scale;
-};
-
-template <class P>
-__global__ __launch_bounds__(512) void attention_bwd_main_kernel(const AttnBwdMainParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = blockIdx.x / p.heads, h = blockIdx.x % p.heads;   // frame, head
-  const int nk = p.n_keys;
-  constexpr int LDK = DH + 1;
-  float* Kf = reinterpret_cast<float*>(smem_raw);      // [nk][65] fp32 K for the dQ product
-  float* Qf = Kf + nk * LDK;                            // [QB][64] fp32 (dK += dS^T Q)
-  float* Of = Qf + AB_QB * DH;                          // [QB][64] fp32 (dV += P^T dO)
-  const int LDS_ = nk + 1;
-  float* Sb = Of + AB_QB * DH;                          // [QB][nk+1]  dS block
-  float* Pb = Sb + AB_QB * LDS_;                        // [QB][nk+1]  P block
-  float* red = Pb + AB_QB * LDS_;                       // [QB][8]
-  unsigned short* Qh = reinterpret_cast<unsigned short*>(red + AB_QB * 8);   // [QB][64] h16 as stored (dot2 operands)
-  unsigned short* Oh = Qh + AB_QB * DH;
-  const long row0 = (long)n * p.n_kmain;                // main rows of this frame (queries are its first n_q rows)
-
-  // ---- a thread PAIR owns key j (adjacent lanes: 32 of the 64 head dims each): K, V packed h16 and the fp32
-  //      dK, dV halves in registers
-  const int j = tid >> 1, hf = tid & 1, d0 = hf * AB_HALF;
-  const bool has_key = j < nk;
-  const bool lead = has_key && hf == 0;                 // one thread of the pair speaks in the row reductions
-  unsigned kp2[AB_HALF / 2], vp2[AB_HALF / 2];
-  float dkr[AB_HALF], dvr[AB_HALF];
-  long side_row = -1;
-#pragma unroll
-  for (int d = 0; d < AB_HALF / 2; ++d) { kp2[d] = 0u; vp2[d] = 0u; }
-#pragma unroll
-  for (int d = 0; d < AB_HALF; ++d) { dkr[d] = 0.f; dvr[d] = 0.f; }
-  if (has_key) {
-    const unsigned short* kp; const unsigned short* vp;
-    if (j < p.n_kmain) {
-      kp = p.k + (row0 + j) * p.ld_qkv + h * DH + d0; vp = p.v + (row0 + j) * p.ld_qkv + h * DH + d0;
-    } else {
-      const int sidx = j - p.n_kmain;
-      side_row = sidx < p.n_g ? sidx
-               : sidx < p.n_g + p.T ? p.n_g + (long)(n / p.T) * p.T + (sidx - p.n_g)
-                                    : (long)p.n_g + p.batch + n;
-      kp = p.sk + side_row * p.ld_side + h * DH + d0; vp = p.sv + side_row * p.ld_side + h * DH + d0;
-    }
-#pragma unroll
-    for (int c = 0; c < AB_HALF / 8; ++c) {
-      const uint4 a = *reinterpret_cast<const uint4*>(kp + 8 * c);
-      const uint4 b = *reinterpret_cast<const uint4*>(vp + 8 * c);
-      kp2[4 * c] = a.x; kp2[4 * c + 1] = a.y; kp2[4 * c + 2] = a.z; kp2[4 * c + 3] = a.w;
-      vp2[4 * c] = b.x; vp2[4 * c + 1] = b.y; vp2[4 * c + 2] = b.z; vp2[4 * c + 3] = b.w;
-    }
-#pragma unroll
-    for (int d = 0; d < AB_HALF / 2; ++d) {
-      Kf[j * LDK + d0 + 2 * d] = P::up((unsigned short)kp2[d]);
-      Kf[j * LDK + d0 + 2 * d + 1] = P::up((unsigned short)(kp2[d] >> 16));
-    }
-  }
-
-  const int nblk = (p.n_q + AB_QB - 1) / AB_QB;
-  for (int blk = 0; blk < nblk; ++blk) {
-    const int i0 = blk * AB_QB;
-    __syncthreads();   // previous block's readers of the row blocks are done (and Kf is complete before its first use)
-    {                  // ---- stage the block's query rows of Q and dO: 8 x 64 = one element per thread
-      const int i = tid >> 6, d = tid & 63;
-      const bool ok = i0 + i < p.n_q;
-      const unsigned short qv = ok ? p.q[(row0 + i0 + i) * p.ld_qkv + h * DH + d] : (unsigned short)0;
-      const unsigned short ov = ok ? p.dout[(row0 + i0 + i) * p.ld_dout + h * DH + d] : (unsigned short)0;
-      Qh[tid] = qv; Oh[tid] = ov;
-      Qf[tid] = P::up(qv); Of[tid] = P::up(ov);
-    }
-    __syncthreads();
-    // ---- S = Q K^T and dP = dO V^T for this key: packed dot products (v_dot2c), pair-summed over the two halves
-    float S[AB_QB], dP[AB_QB];
-#pragma unroll
-    for (int i = 0; i < AB_QB; ++i) {
-      float s = 0.f, t = 0.f;
-#pragma unroll
-      for (int c = 0; c < AB_HALF / 8; ++c) {
-        const uint4 qv = *reinterpret_cast<const uint4*>(Qh + i * DH + d0 + 8 * c);
-        const uint4 ov = *reinterpret_cast<const uint4*>(Oh + i * DH + d0 + 8 * c);
-        s = P::dot2(qv.x, kp2[4 * c], s); s = P::dot2(qv.y, kp2[4 * c + 1], s);
-        s = P::dot2(qv.z, kp2[4 * c + 2], s); s = P::dot2(qv.w, kp2[4 * c + 3], s);
-        t = P::dot2(ov.x, vp2[4 * c], t); t = P::dot2(ov.y, vp2[4 * c + 1], t);
-        t = P::dot2(ov.z, vp2[4 * c + 2], t); t = P::dot2(ov.w, vp2[4 * c + 3], t);
-      }
-      s += __shfl_xor(s, 1, 64);
-      t += __shfl_xor(t, 1, 64);
-      S[i] = has_key ? s : -INFINITY;
-      dP[i] = t;
-    }
-    // ---- softmax over keys (across the workgroup), then dS = P * (dP - rowsum(P * dP))
-    auto reduce_rows = [&](float (&x)[AB_QB], bool is_max) {
-#pragma unroll
-      for (int i = 0; i < AB_QB; ++i) {
-        float v = x[i];
-#pragma unroll
-        for (int o = 32; o; o >>= 1) { const float w = __shfl_xor(v, o, 64); v = is_max ? fmaxf(v, w) : v + w; }
-        if (lane == 0) red[i * 8 + wave] = v;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < AB_QB; ++i) {
-        const float4 r0 = *reinterpret_cast<const float4*>(red + i * 8);
-        const float4 r1 = *reinterpret_cast<const float4*>(red + i * 8 + 4);
-        x[i] = is_max ? fmaxf(fmaxf(fmaxf(r0.x, r0.y), fmaxf(r0.z, r0.w)), fmaxf(fmaxf(r1.x, r1.y), fmaxf(r1.z, r1.w)))
-                      : ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w));
-      }
-      __syncthreads();
-    };
-    float m[AB_QB];
-#pragma unroll
-    for (int i = 0; i < AB_QB; ++i) m[i] = S[i];
-    reduce_rows(m, true);
-#pragma unroll
-    for (int i = 0; i < AB_QB; ++i) { S[i] = has_key ? __expf(S[i] - m[i]) : 0.f; m[i] = lead ? S[i] : 0.f; }
-    reduce_rows(m, false);
-#pragma unroll
-    for (int i = 0; i < AB_QB; ++i) { S[i] = S[i] / m[i]; m[i] = lead ? S[i] * dP[i] : 0.f; }   // S is P now
-    reduce_rows(m, false);
-#pragma unroll
-    for (int i = 0; i < AB_QB; ++i) {
-      const bool ok = has_key && i0 + i < p.n_q;
-      S[i] = ok ? S[i] : 0.f;
-      dP[i] = ok ? S[i] * (dP[i] - m[i]) : 0.f;                                      // dP is dS now
-      if (lead) { Sb[i * LDS_ + j] = dP[i]; Pb[i * LDS_ + j] = S[i]; }
-    }
-    __syncthreads();
-    // ---- dV += P^T dO, dK += dS^T Q (own key, own half, registers).  A real loop over the rows, P / dS re-read from
-    //      LDS: fully unrolled, the compiler hoists all 8 rows of Q and dO into registers at once and spills.
-    if (has_key) {
-#pragma unroll 1
-      for (int i = 0; i < AB_QB; ++i) {
-        const float ds = Sb[i * LDS_ + j], pj = Pb[i * LDS_ + j];
-#pragma unroll
-        for (int d = 0; d < AB_HALF; d += 4) {
-          const float4 qv = *reinterpret_cast<const float4*>(Qf + i * DH + d0 + d);
-          dkr[d] += ds * qv.x; dkr[d + 1] += ds * qv.y; dkr[d + 2] += ds * qv.z; dkr[d + 3] += ds * qv.w;
-        }
-#pragma unroll
-        for (int d = 0; d < AB_HALF; d += 4) {
-          const float4 ov = *reinterpret_cast<const float4*>(Of + i * DH + d0 + d);
-          dvr[d] += pj * ov.x; dvr[d + 1] += pj * ov.y; dvr[d + 2] += pj * ov.z; dvr[d + 3] += pj * ov.w;
-        }
-      }
-    }
-    // ---- dQ[i][d] = q_scale * sum_j dS[i][j] K[j][d]: thread = (d = lane, row = wave)
-    {
-      const int d = lane, i = i0 + wave;
-      float a0 = 0.f, a1 = 0.f;
-      int jj = 0;
-      for (; jj + 1 < nk; jj += 2) {
-        a0 += Sb[wave * LDS_ + jj] * Kf[jj * LDK + d];
-        a1 += Sb[wave * LDS_ + jj + 1] * Kf[(jj + 1) * LDK + d];
-      }
-      if (jj < nk) a0 += Sb[wave * LDS_ + jj] * Kf[jj * LDK + d];
-      if (i < p.n_q) p.dq[(row0 + i) * p.ld_dqkv + h * DH + d] = P::cvt((a0 + a1) * p.q_scale);
-    }
-  }
-  // ---- key gradients: own rows as h16, prompt rows by fp32 atomics
-  if (has_key) {
-    if (j < p.n_kmain) {
-      unsigned short* ok = p.dk + (row0 + j) * p.ld_dqkv + h * DH + d0;
-      unsigned short* ov = p.dv + (row0 + j) * p.ld_dqkv + h * DH + d0;
-#pragma unroll
-      for (int d = 0; d < AB_HALF; d += 4) {
-        *reinterpret_cast<uint2*>(ok + d) = pack4<P>(dkr[d], dkr[d + 1], dkr[d + 2], dkr[d + 3]);
-        *reinterpret_cast<uint2*>(ov + d) = pack4<P>(dvr[d], dvr[d + 1], dvr[d + 2], dvr[d + 3]);
-      }
-    } else {
-      // per-frame partial of a shared prompt row: plain stores, the caller sums over the frames that share the row
-      // (atomics into the shared rows cost 30x the arithmetic: 512 frames x 12 heads contend for the global prompts)
-      const long pr = (long)n * (nk - p.n_kmain) + (j - p.n_kmain);
-      float* ok = p.dsk + pr * p.ld_dside + h * DH + d0;
-      float* ov = p.dsv + pr * p.ld_dside + h * DH + d0;
-#pragma unroll
-      for (int d = 0; d < AB_HALF; d += 4) {
-        *reinterpret_cast<float4*>(ok + d) = make_float4(dkr[d], dkr[d + 1], dkr[d + 2], dkr[d + 3]);
-        *reinterpret_cast<float4*>(ov + d) = make_float4(dvr[d], dvr[d + 1], dvr[d + 2], dvr[d + 3]);
-      }
-    }
-  }
-}
-
 }  // namespace
 
 extern "C" int gava_layernorm_backward(const gava_layernorm_bwd_args* a, gava_stream_t stream) {
@@ -447,31 +243,30 @@ extern "C" int gava_attention_backward(const gava_attention_bwd_args* a, gava_st
     GAVA_CHECK_LAUNCH();
     return GAVA_OK;
   }
-  // vision blocks: n main rows per frame, the first n_q of them query (0 = all), prompt rows gathered as in gava_attention
-  if (a->causal) return GAVA_EINVAL;
+  // vision blocks: n main rows per frame, the first n_q of them query (0 = all), prompt rows gathered as in
+  // gava_attention: MFMA kernels (attention_bwd.hip)
+  if (a->causal || !a->workspace) return GAVA_EINVAL;
   if (n_side && (!a->side_v || !a->dside_k || !a->dside_v || a->n_g < 0 || a->T <= 0 || a->batch % a->T)) return GAVA_EINVAL;
-  if ((a->ld_qkv | a->ld_side) % 8) return GAVA_EINVAL;
-  if ((((uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->side_k | (uintptr_t)a->side_v | (uintptr_t)a->dside_k | (uintptr_t)a->dside_v) & 15) ||
-      (a->ld_dqkv % 4) || (a->ld_dside % 4)) return GAVA_EINVAL;
-  AttnBwdMainParams p;
+  if ((a->ld_qkv | a->ld_side | a->ld_dout) % 8) return GAVA_EINVAL;
+  if ((((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->dout | (uintptr_t)a->side_k | (uintptr_t)a->side_v |
+        (uintptr_t)a->dside_k | (uintptr_t)a->dside_v) & 15) || (a->ld_dqkv % 4) || (a->ld_dside % 4)) return GAVA_EINVAL;
+  if ((((uintptr_t)a->dq | (uintptr_t)a->dk | (uintptr_t)a->dv) & 7)) return GAVA_EINVAL;
+  gava::AttnBwdMfmaParams p;
   p.q = (const unsigned short*)a->q; p.k = (const unsigned short*)a->k; p.v = (const unsigned short*)a->v; p.ld_qkv = a->ld_qkv;
   p.sk = (const unsigned short*)a->side_k; p.sv = (const unsigned short*)a->side_v; p.ld_side = a->ld_side;
   p.dout = (const unsigned short*)a->dout; p.ld_dout = a->ld_dout;
   p.dq = (unsigned short*)a->dq; p.dk = (unsigned short*)a->dk; p.dv = (unsigned short*)a->dv; p.ld_dqkv = a->ld_dqkv;
   p.dsk = a->dside_k; p.dsv = a->dside_v; p.ld_dside = a->ld_dside;
+  p.stats = (float*)a->workspace;
   p.batch = a->batch; p.heads = a->heads; p.n_q = a->n_q ? a->n_q : a->n; p.n_kmain = a->n;
   p.n_g = a->n_g; p.T = n_side ? a->T : 1; p.has_summary = a->has_summary; p.n_keys = a->n + n_side;
+  p.q_pad = ((p.n_q + 15) / 16 + 1) / 2 * 32;
   p.q_scale = a->q_scale;
-  if (p.n_keys > AB_MAXK || p.n_q > a->n) return GAVA_EINVAL;
-  const size_t lds = (size_t)(p.n_keys * (DH + 1) + 2 * AB_QB * DH + 2 * AB_QB * (p.n_keys + 1) + AB_QB * 8) * sizeof(float) + 2 * AB_QB * DH * sizeof(unsigned short);
-  dim3 grid(a->batch * a->heads), block(512);
-  if (a->prec == GAVA_PREC_F16) {
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)attention_bwd_main_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GAVA_ELAUNCH;
-    hipLaunchKernelGGL(attention_bwd_main_kernel<PrecF16>, grid, block, lds, s, p);
-  } else {
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)attention_bwd_main_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GAVA_ELAUNCH;
-    hipLaunchKernelGGL(attention_bwd_main_kernel<PrecBF16>, grid, block, lds, s, p);
-  }
-  GAVA_CHECK_LAUNCH();
-  return GAVA_OK;
+  if (p.n_keys > 320 || p.n_q > a->n || p.n_q > 288) return GAVA_EINVAL;
+  return gava::attention_bwd_mfma(p, a->prec, s);
+}
+
+extern "C" size_t gava_attention_backward_workspace_bytes(int batch, int heads, int n_q) {
+  if (batch <= 0 || heads <= 0 || n_q <= 0) return 0;
+  return (size_t)batch * heads * (((n_q + 15) / 16 + 1) / 2 * 32) * 2 * sizeof(float);
 }

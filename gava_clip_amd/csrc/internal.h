@@ -12,6 +12,19 @@ int copy_rows(const float* in, long in_stride, float* out, int rows, int D, hipS
 int text_embed(const float* emb, const float* pos, const float* ctx, const int* tok, float* X,
                int n_prompts, int L, int W, int n_ctx, hipStream_t s);
 unsigned long long* debug_buffer();
+
+// MFMA attention backward (attention_bwd.hip), launched by gava_attention_backward (backward.hip)
+struct AttnBwdMfmaParams {
+  const unsigned short* q; const unsigned short* k; const unsigned short* v; long ld_qkv;
+  const unsigned short* sk; const unsigned short* sv; long ld_side;
+  const unsigned short* dout; long ld_dout;
+  unsigned short* dq; unsigned short* dk; unsigned short* dv; long ld_dqkv;
+  float* dsk; float* dsv; long ld_dside;
+  float* stats;                 // [batch*heads][q_pad][2]: log2-sum-exp and delta per query
+  int batch, heads, n_q, n_kmain, n_g, T, has_summary, n_keys, q_pad;
+  float q_scale;
+};
+int attention_bwd_mfma(const AttnBwdMfmaParams& p, int prec, hipStream_t s);
 // CUs the persistent GEMM leaves free on its next launches (so a concurrent stream can run small kernels)
 void set_gemm_cu_reserve(int n);
 int gemm_cu_reserve();   // set by gava_debug_set_buffer; nullptr = stamps off

@@ -20,7 +20,7 @@ EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_vision_workspace_bytes", "gava_vision_forward", "gava_text_workspace_bytes",
            "gava_text_forward", "gava_similarity_head", "gava_convert_h16", "gava_debug_set_buffer",
            "gava_preprocess_clip", "gava_layernorm_backward", "gava_qgelu_backward", "gava_attention_backward",
-           "gava_text_forward_train", "gava_vision_forward_train"]
+           "gava_text_forward_train", "gava_vision_forward_train", "gava_attention_backward_workspace_bytes"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 
@@ -100,7 +100,7 @@ class AttentionBwdArgs(C.Structure):
                 ("q_scale", C.c_float),
                 ("side_k", _vp), ("side_v", _vp), ("ld_side", C.c_int64),
                 ("dside_k", _fp), ("dside_v", _fp), ("ld_dside", C.c_int64),
-                ("n_g", C.c_int), ("T", C.c_int), ("has_summary", C.c_int), ("n_q", C.c_int)]
+                ("n_g", C.c_int), ("T", C.c_int), ("has_summary", C.c_int), ("n_q", C.c_int), ("workspace", _vp)]
 
 
 _lib = None
@@ -149,6 +149,8 @@ def load():
     lib.gava_qgelu_backward.restype = C.c_int
     lib.gava_attention_backward.argtypes = [C.POINTER(AttentionBwdArgs), _vp]
     lib.gava_attention_backward.restype = C.c_int
+    lib.gava_attention_backward_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.gava_attention_backward_workspace_bytes.restype = C.c_size_t
     lib.gava_vision_forward_train.argtypes = [C.POINTER(VisionModel), _fp, _fp, _fp, _fp, _fp, _vp, C.c_size_t, _vp]
     lib.gava_vision_forward_train.restype = C.c_int
     lib.gava_text_forward_train.argtypes = [C.POINTER(TextModel), _ip, _fp, _ip, _fp, _fp, _vp, C.c_size_t, _vp]
@@ -274,6 +276,10 @@ def attention_backward(q, k, v, dout, dq, dk, dv, *, batch, heads, n, prec, caus
     a.dside_k, a.dside_v = ptr(dside_k), ptr(dside_v)
     a.ld_dside = dside_k.stride(0) if dside_k is not None else 0
     a.n_g, a.T, a.has_summary, a.n_q = n_g, T, int(has_summary), n_q
+    ws = None
+    if side_k is not None or n > 88:
+        ws = torch.empty(load().gava_attention_backward_workspace_bytes(batch, heads, n_q or n), dtype=torch.uint8, device=q.device)
+    a.workspace = ptr(ws)
     a.q, a.k, a.v, a.ld_qkv = ptr(q), ptr(k), ptr(v), q.stride(0)
     a.dout, a.ld_dout = ptr(dout), dout.stride(0)
     a.dq, a.dk, a.dv, a.ld_dqkv = ptr(dq), ptr(dk), ptr(dv), dq.stride(0)

@@ -222,7 +222,8 @@ int gava_qgelu_backward(const void* pre, const void* dh, void* dpre, size_t n, i
  *     gava_attention); n + prompts <= 256.  Prompt rows are shared between frames, so their gradients come out as
  *     per-frame partials dside_k / dside_v fp32 [batch][n_g + T + 1][ld_dside] (plain stores; row order global,
  *     local, summary) which the caller sums over the frames sharing a row.  n_q != 0: only the first n_q rows of
- *     each frame are queries. */
+ *     each frame are queries.  `workspace`: gava_attention_backward_workspace_bytes(batch, heads, n_q) bytes of
+ *     scratch (per-query softmax statistics handed from the dQ kernel to the dK/dV kernel). */
 typedef struct {
   const void* q; const void* k; const void* v; int64_t ld_qkv;
   const void* dout; int64_t ld_dout;
@@ -232,8 +233,10 @@ typedef struct {
   const void* side_k; const void* side_v; int64_t ld_side;
   float* dside_k; float* dside_v; int64_t ld_dside;
   int n_g, T, has_summary, n_q;
+  void* workspace;
 } gava_attention_bwd_args;
 int gava_attention_backward(const gava_attention_bwd_args* a, gava_stream_t stream);
+size_t gava_attention_backward_workspace_bytes(int batch, int heads, int n_q);
 
 /* gava_text_forward that also keeps what the backward recomputes from: saved_x fp32 [layers+1][n_prompts*L][W] =
  * the input of every residual block and the final stream (before ln_final). */

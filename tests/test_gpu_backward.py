@@ -174,16 +174,16 @@ def test_attention_backward_vision_with_prompt_rows_matches_autograd(BT, T, head
                            batch=BT, heads=heads, n=n, prec=BF, q_scale=0.125,
                            side_k=sd_[:, :D], side_v=sd_[:, D:], dside_k=dside[:, :D], dside_v=dside[:, D:],
                            n_g=G, T=T, has_summary=True, n_q=n_q)
-    tol = 2 ** -8 * 1.05
+    tol = 3 * 2 ** -8     # P and dS are rounded to bf16 between the two MFMA products (as P is in the forward kernel)
     ref_q = q32.grad.view(BT, n, D)[:, :nq]
     got_q = dqkv[:, :D].float().cpu().view(BT, n, D)[:, :nq]
     assert (got_q - ref_q).abs().max() <= tol * ref_q.abs().max() + 1e-6
     for name, got, ref in (("dk", dqkv[:, D:2 * D].float().cpu(), k32.grad), ("dv", dqkv[:, 2 * D:].float().cpu(), v32.grad)):
         assert (got - ref).abs().max() <= tol * ref.abs().max() + 1e-6, name
-    # prompt rows: per-frame fp32 partials, summed here over the frames that share a row (no 16-bit rounding)
+    # prompt rows: per-frame fp32 partials, summed here over the frames that share a row
     pv = part.cpu().view(BT // T, T, G + T + 1, 2 * D)
     total = torch.cat([pv[:, :, :G].sum(dim=(0, 1)), pv[:, :, G:G + T].sum(dim=1).reshape(BT, 2 * D), pv[:, :, G + T].reshape(BT, 2 * D)])
-    assert (total - s32.grad).abs().max() <= 2e-3 * s32.grad.abs().max(), "dside"
+    assert (total - s32.grad).abs().max() <= tol * s32.grad.abs().max(), "dside"
 
 
 def _oracle_all_grads(cfg, sd, tokens, x, wlog):

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p gava_clip_amd/build/$name
-for f in gemm attention rowops forward preprocess backward; do
+for f in gemm attention rowops forward preprocess backward attention_bwd; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c gava_clip_amd/csrc/$f.hip -o gava_clip_amd/build/$name/$f.o &
 done
 wait
