@@ -59,6 +59,45 @@ def sharded_forward_gpu(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def ddp_train_gpu(rank, world, port, out_dir):
+    """DistributedDataParallel around the drop-in model as training/train.py:347 does: each rank backpropagates its
+    own clips through the HIP backward, DDP averages the gradients (gloo here; RCCL on a multi-GPU node).  The
+    averaged gradients must equal those of one process on the concatenated batch with the loss averaged."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from gava_clip_amd import VitaCLIP, synth
+    from gava_clip_amd.config import TINY
+    from helpers import model_kwargs, synth_torch_state
+    _init(rank, world, port)
+    torch.set_num_threads(2)
+    b = 2
+    x = torch.from_numpy(synth.synth_clip(b * world, TINY.num_frames, TINY.input_size)).cuda()
+    y = torch.arange(b * world, device="cuda") % 3
+
+    def fresh():
+        m = VitaCLIP(**model_kwargs(TINY))
+        m.load_state_dict(synth_torch_state(TINY, 3), strict=True)
+        return m.cuda().train()
+
+    ddp = DDP(fresh(), find_unused_parameters=False)
+    logits = ddp(x[rank * b:(rank + 1) * b])[0]
+    torch.nn.functional.cross_entropy(logits, y[rank * b:(rank + 1) * b]).backward()
+    torch.cuda.synchronize()
+    single = fresh()
+    torch.nn.functional.cross_entropy(single(x)[0], y).backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    n = 0
+    for (name, p), (_, q) in zip(ddp.module.named_parameters(), single.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None, name
+            continue
+        n += 1
+        worst = max(worst, float((p.grad - q.grad).norm() / (q.grad.norm() + 1e-12)))
+    np.save(os.path.join(out_dir, f"ddp{rank}.npy"), np.array([worst, n]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     fn, rank, world, port, out_dir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-    {"gather_cpu": gather_cpu, "sharded_forward_gpu": sharded_forward_gpu}[fn](rank, world, port, out_dir)
+    {"gather_cpu": gather_cpu, "sharded_forward_gpu": sharded_forward_gpu, "ddp_train_gpu": ddp_train_gpu}[fn](rank, world, port, out_dir)
