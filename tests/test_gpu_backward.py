@@ -138,7 +138,9 @@ def test_text_prompt_gradients_match_oracle_autograd(cfg, B):
     assert not torch.equal(l2, logits.detach())
 
 
-@pytest.mark.parametrize("BT,T,heads,n,G,n_q", [(16, 8, 12, 197, 8, 0), (8, 4, 2, 17, 4, 0), (4, 2, 3, 33, 0, 0), (8, 8, 2, 50, 8, 1)])
+@pytest.mark.parametrize("BT,T,heads,n,G,n_q", [(16, 8, 12, 197, 8, 0), (8, 4, 2, 17, 4, 0), (4, 2, 3, 33, 0, 0), (8, 8, 2, 50, 8, 1),
+                                                 (32, 32, 2, 257, 8, 0),     # ViT-L/14, T = 32: 298 keys, 17 query tiles
+                                                 (16, 16, 2, 197, 8, 0)])    # T = 16: 222 keys
 def test_attention_backward_vision_with_prompt_rows_matches_autograd(BT, T, heads, n, G, n_q):
     """Vision block attention (vision_encoder_utils.py:176-191): keys = the frame's n rows + G global prompt rows +
     the T local-prompt rows of its clip + its summary row.  dq/dk/dv of the frame rows and the ACCUMULATED gradients of
