@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the stand-alone kernel timings")
     ap.add_argument("--no-alt", action="store_true", help="skip the short run in the other operand dtype")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement")
     return ap.parse_args()
 
 
@@ -256,6 +257,23 @@ def main():
         model.set_operand_dtype(a.prec)
         if s2 is not None:
             out["alt"] = {"dtype": other, "value": round(B * max(3, a.steps // 4) / s2, 2), "unit": "clips/s"}
+    if rank == 0 and world == 1 and not a.no_train:
+        # one training step (forward with saved block inputs, loss.backward() through the HIP
+        # backward kernels, AdamW on the trainable subset), same batch.  Reported beside the headline, not part of it.
+        log("training step")
+        model.train()
+        y = torch.randint(0, n_cls, (B,), device="cuda", generator=gen)
+        opt = torch.optim.AdamW([q for q in model.parameters() if q.requires_grad], lr=1e-5)
+
+        def train_step():
+            opt.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(model(x)[0], y).backward()
+            opt.step()
+        ts = timed_steps(train_step, 3, 2, None)
+        model.eval()
+        out["train_step"] = {"ms_per_step": round(1e3 * ts / 3, 1), "value": round(3 * B / ts, 1), "unit": "clips/s",
+                             "what": "forward + backward (bf16 gradient operands) + AdamW, %d trainable parameters"
+                                     % sum(q.numel() for q in model.parameters() if q.requires_grad)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if dist is not None:

@@ -20,9 +20,11 @@ struct LnBwdParams {
   const float* dy; long dy_stride;
   float* dx; long dx_stride; const int* dx_idx;         // optionally scattered
   float* dgamma; float* dbeta;                          // optional, fp32 [D], accumulated with atomics
+  unsigned short* dx16; long dx16_stride;               // optional h16 copy of the (accumulated) dx: next dgrad's operand
   int rows, D, accumulate;
 };
 
+template <class P>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LnBwdParams p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LnBwdParams p)
         o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
       }
       *reinterpret_cast<float4*>(dxr + c) = o;
+      if (p.dx16) *reinterpret_cast<uint2*>(p.dx16 + (long)row * p.dx16_stride + c) = pack4<P>(o.x, o.y, o.z, o.w);
     }
 }
 
@@ -198,9 +201,12 @@ extern "C" int gava_layernorm_backward(const gava_layernorm_bwd_args* a, gava_st
   if (a->rows <= 0 || a->D <= 0 || a->D % 4 || a->D > MAXV * 256) return GAVA_EINVAL;
   if ((a->dgamma == nullptr) != (a->dbeta == nullptr)) return GAVA_EINVAL;
   if (a->x_stride % 4 || a->dy_stride % 4 || a->dx_stride % 4) return GAVA_EINVAL;
+  if (a->dx16 && (a->dx_row_index || a->dx16_stride % 4 || (a->prec != GAVA_PREC_F16 && a->prec != GAVA_PREC_BF16))) return GAVA_EINVAL;
   LnBwdParams p{a->x, a->x_stride, a->x_row_index, a->gamma, a->dy, a->dy_stride, a->dx, a->dx_stride,
-                a->dx_row_index, a->dgamma, a->dbeta, a->rows, a->D, a->accumulate};
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+                a->dx_row_index, a->dgamma, a->dbeta, (unsigned short*)a->dx16, a->dx16_stride, a->rows, a->D, a->accumulate};
+  dim3 grid((a->rows + 3) / 4), block(256);
+  if (a->dx16 && a->prec == GAVA_PREC_F16) hipLaunchKernelGGL(layernorm_bwd_kernel<PrecF16>, grid, block, 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<PrecBF16>, grid, block, 0, (hipStream_t)stream, p);
   GAVA_CHECK_LAUNCH();
   return GAVA_OK;
 }

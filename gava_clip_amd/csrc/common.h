@@ -86,6 +86,12 @@ static __device__ __forceinline__ float quick_gelu(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
 }
 
+static __device__ __forceinline__ float quick_gelu_grad(float x) {
+  // d/dx [x * s(1.702 x)] = s * (1 + 1.702 x (1 - s))
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+  return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+
 #define GAVA_CHECK_LAUNCH()                                   \
   do {                                                        \
     if (hipGetLastError() != hipSuccess) return GAVA_ELAUNCH; \

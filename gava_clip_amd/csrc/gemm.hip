@@ -36,6 +36,7 @@ struct GemmParams {
   const float* bias;
   void* out; long ldo;
   const float* resid; long ldr;
+  const unsigned short* aux;   // EPI_H16_QGELU_BWD: pre-activations, laid out as out
   int M, N, K;
   int scale_cols; float scale;
   const float* pos; const float* time; int n_patches; int T;
@@ -255,11 +256,15 @@ void gemm_kernel(const GemmParams p) {
       const int n = nbase + j * 16;
       float v0 = acc[i][j][0] + bj[j].x, v1 = acc[i][j][1] + bj[j].y;
       float v2 = acc[i][j][2] + bj[j].z, v3 = acc[i][j][3] + bj[j].w;
-      if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU) {
+      if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU || EPI == GAVA_EPI_H16_QGELU_BWD) {
         if (EPI == GAVA_EPI_H16) {
           if (n < p.scale_cols) { v0 *= p.scale; v1 *= p.scale; v2 *= p.scale; v3 *= p.scale; }
-        } else {
+        } else if (EPI == GAVA_EPI_H16_QGELU) {
           v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3);
+        } else {
+          const uint2 ax = *reinterpret_cast<const uint2*>(p.aux + orow * p.ldo + n);
+          v0 *= quick_gelu_grad(P::up((unsigned short)ax.x)); v1 *= quick_gelu_grad(P::up((unsigned short)(ax.x >> 16)));
+          v2 *= quick_gelu_grad(P::up((unsigned short)ax.y)); v3 *= quick_gelu_grad(P::up((unsigned short)(ax.y >> 16)));
         }
         unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + n;
         if (SPLIT) {
@@ -307,6 +312,7 @@ int launch_tile(GemmParams gp, int epi, hipStream_t s) {
       if (gp.resid) GAVA_LAUNCH(GAVA_EPI_F32, true, false); else GAVA_LAUNCH(GAVA_EPI_F32, false, false);
       break;
     case GAVA_EPI_F32_PATCH: GAVA_LAUNCH(GAVA_EPI_F32_PATCH, false, false); break;
+    case GAVA_EPI_H16_QGELU_BWD: GAVA_LAUNCH(GAVA_EPI_H16_QGELU_BWD, false, false); break;
     default: return GAVA_EINVAL;
   }
 #undef GAVA_LAUNCH
@@ -530,15 +536,24 @@ void gemm256_kernel(const GemmParams p) {
           v[4 * jj + 0] = acc[i][jj][0] + bj[jj].x; v[4 * jj + 1] = acc[i][jj][1] + bj[jj].y;
           v[4 * jj + 2] = acc[i][jj][2] + bj[jj].z; v[4 * jj + 3] = acc[i][jj][3] + bj[jj].w;
         }
-        if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU) {
+        if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU || EPI == GAVA_EPI_H16_QGELU_BWD) {
           if (EPI == GAVA_EPI_H16) {
             if (nb0 < p.scale_cols) {
 #pragma unroll
               for (int e = 0; e < 16; ++e) v[e] *= p.scale;
             }
-          } else {
+          } else if (EPI == GAVA_EPI_H16_QGELU) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = quick_gelu(v[e]);
+          } else {
+            const unsigned short* axp = p.aux + orow * p.ldo + nb0;
+            const uint4 a0 = *reinterpret_cast<const uint4*>(axp), a1 = *reinterpret_cast<const uint4*>(axp + 8);
+            const unsigned aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[2 * e] *= quick_gelu_grad(P::up((unsigned short)aw[e]));
+              v[2 * e + 1] *= quick_gelu_grad(P::up((unsigned short)(aw[e] >> 16)));
+            }
           }
           unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + nb0;
           if (SPLIT) {
@@ -1217,6 +1232,10 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
       if (gp.resid) GAVA_LAUNCH(GAVA_EPI_F32, true, false); else GAVA_LAUNCH(GAVA_EPI_F32, false, false);
       break;
     case GAVA_EPI_F32_PATCH: GAVA_LAUNCH(GAVA_EPI_F32_PATCH, false, false); break;
+    case GAVA_EPI_H16_QGELU_BWD:
+      if (KERN != 3) return GAVA_EINVAL;
+      hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_H16_QGELU_BWD, false, false>), grid, block, 0, s, gp);
+      break;
     default: return GAVA_EINVAL;
   }
 #undef GAVA_LAUNCH
@@ -1265,6 +1284,7 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   if (a->bias && ((uintptr_t)a->bias & 15)) return GAVA_EINVAL;
   if (a->ldo % 4 || a->ldo < (a->split_out ? 3 : 1) * (int64_t)a->N) return GAVA_EINVAL;
   if (a->split_out && a->epilogue != GAVA_EPI_H16 && a->epilogue != GAVA_EPI_H16_QGELU) return GAVA_EINVAL;
+  if (a->epilogue == GAVA_EPI_H16_QGELU_BWD && (!a->aux || ((uintptr_t)a->aux & 15) || a->ldo % 8)) return GAVA_EINVAL;
   if (a->epilogue == GAVA_EPI_F32 && a->resid && (a->ldr % 4 || ((uintptr_t)a->resid & 15))) return GAVA_EINVAL;
   if (a->epilogue == GAVA_EPI_F32_PATCH &&
       (!a->pos || !a->time || a->n_patches <= 0 || a->T <= 0 || a->M % a->n_patches)) return GAVA_EINVAL;
@@ -1273,6 +1293,7 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.W = (const unsigned short*)a->W; gp.ldw = a->ldw;
   gp.bias = a->bias; gp.out = a->out; gp.ldo = a->ldo;
   gp.resid = a->resid; gp.ldr = a->ldr;
+  gp.aux = (const unsigned short*)a->aux;
   gp.M = a->M; gp.N = a->N; gp.K = a->K;
   gp.scale_cols = a->scale_cols; gp.scale = a->scale;
   gp.pos = a->pos; gp.time = a->time; gp.n_patches = a->n_patches; gp.T = a->T;

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAVA_HIP_LIB") or os.path.join(_HERE, "libgava_hip.so")   # env: A/B experiment builds only
 
 PREC_F16, PREC_BF16 = 0, 1
-EPI_H16, EPI_H16_QGELU, EPI_F32, EPI_F32_PATCH = 0, 1, 2, 3
+EPI_H16, EPI_H16_QGELU, EPI_F32, EPI_F32_PATCH, EPI_H16_QGELU_BWD = 0, 1, 2, 3, 4
 PREC_NAMES = {"fp16": PREC_F16, "f16": PREC_F16, "bf16": PREC_BF16}
 PREC_TORCH = {PREC_F16: torch.float16, PREC_BF16: torch.bfloat16}
 
@@ -31,7 +31,8 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int), ("prec", C.c_int),
                 ("scale_cols", C.c_int), ("scale", C.c_float),
                 ("pos", _fp), ("time", _fp), ("n_patches", C.c_int), ("T", C.c_int),
-                ("frames", _fp), ("frame_size", C.c_int), ("patch", C.c_int), ("split_out", C.c_int)]
+                ("frames", _fp), ("frame_size", C.c_int), ("patch", C.c_int), ("split_out", C.c_int),
+                ("aux", _vp)]
 
 
 class LayerNormArgs(C.Structure):
@@ -90,7 +91,8 @@ class LayerNormBwdArgs(C.Structure):
     _fields_ = [("x", _fp), ("x_stride", C.c_int64), ("x_row_index", _ip), ("gamma", _fp),
                 ("dy", _fp), ("dy_stride", C.c_int64),
                 ("dx", _fp), ("dx_stride", C.c_int64), ("dx_row_index", _ip),
-                ("dgamma", _fp), ("dbeta", _fp), ("rows", C.c_int), ("D", C.c_int), ("accumulate", C.c_int)]
+                ("dgamma", _fp), ("dbeta", _fp), ("rows", C.c_int), ("D", C.c_int), ("accumulate", C.c_int),
+                ("dx16", _vp), ("dx16_stride", C.c_int64), ("prec", C.c_int)]
 
 
 class AttentionBwdArgs(C.Structure):
@@ -183,8 +185,9 @@ def h16_dtype(prec):
 # ---- thin per-op wrappers (used by the unit tests; the model uses the fused drivers) ----------
 
 def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0,
-         pos=None, time=None, n_patches=0, T=0, M=None, split_out=False, frames=None, frame_size=0, patch=0):
+         pos=None, time=None, n_patches=0, T=0, M=None, split_out=False, frames=None, frame_size=0, patch=0, aux=None):
     a = GemmArgs()
+    a.aux = ptr(aux)
     a.A, a.lda, a.W, a.ldw = ptr(A), (A.stride(0) if A is not None else W.stride(0)), ptr(W), W.stride(0)
     a.frames, a.frame_size, a.patch = ptr(frames), frame_size, patch
     a.bias, a.out, a.ldo = ptr(bias), ptr(out), out.stride(0)
@@ -253,8 +256,9 @@ def preprocess_clip(frames_u8, out, *, T, rate, size, mean, std):
 # ---- backward ops ------------------------------------------------------------
 
 def layernorm_backward(x, gamma, dy, dx, *, accumulate=False, x_row_index=None, dx_row_index=None, rows=None,
-                       dgamma=None, dbeta=None):
+                       dgamma=None, dbeta=None, dx16=None, prec=PREC_BF16):
     a = LayerNormBwdArgs()
+    a.dx16, a.dx16_stride, a.prec = ptr(dx16), (dx16.stride(0) if dx16 is not None else 0), prec
     a.x, a.x_stride, a.x_row_index = ptr(x), x.stride(0), ptr(x_row_index)
     a.gamma, a.dy, a.dy_stride = ptr(gamma), ptr(dy), dy.stride(0)
     a.dx, a.dx_stride, a.dx_row_index = ptr(dx), dx.stride(0), ptr(dx_row_index)

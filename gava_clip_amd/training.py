@@ -94,6 +94,7 @@ def text_backward(model, saved, dtext):
     xn, qkv, mix, pre = new(R, W), new(R, 3 * W), new(R, W), new(R, 4 * W)
     X1, dx16, dhid, dmix, dqkv = new(R, W, dtype=torch.float32), new(R, W), new(R, 4 * W), new(R, W), new(R, 3 * W)
     dxn = new(R, W, dtype=torch.float32)
+    hip.check(hip.load().gava_convert_h16(hip.ptr(dX), hip.ptr(dx16), dX.numel(), BWD, hip.stream_ptr()), "convert")
     for i in reversed(range(sh["TL"])):
         P, X0 = bw["layers"][i], saved[i]
         # ---- recompute the block from its input (forward kernels, bf16 operands)
@@ -104,18 +105,16 @@ def text_backward(model, saved, dtext):
         hip.layernorm(X1, P["ln2_g"], P["ln2_b"], out16=xn, prec=BWD)
         hip.gemm(xn, P["w_fc"], P["b_fc"], pre, epilogue=hip.EPI_H16, prec=BWD)
         # ---- MLP branch: x2 = x1 + c_proj(gelu(c_fc(ln_2 x1)))            (VitaCLIP_text_encoder.py:73-77,86)
-        hip.load().gava_convert_h16(hip.ptr(dX), hip.ptr(dx16), dX.numel(), BWD, hip.stream_ptr())
-        hip.gemm(dx16, P["w_proj_t"], None, dhid, epilogue=hip.EPI_H16, prec=BWD)
-        hip.qgelu_backward(pre, dhid, dhid, BWD)
+        #      (dx16 = bf16 copy of dX, written by the LayerNorm' that produced dX)
+        hip.gemm(dx16, P["w_proj_t"], None, dhid, epilogue=hip.EPI_H16_QGELU_BWD, prec=BWD, aux=pre)   # c_proj^T, gelu' fused
         hip.gemm(dhid, P["w_fc_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)
-        hip.layernorm_backward(X1, P["ln2_g"], dxn, dX, accumulate=True)
+        hip.layernorm_backward(X1, P["ln2_g"], dxn, dX, accumulate=True, dx16=dx16)
         # ---- attention branch: x1 = x0 + out_proj(attn(in_proj(ln_1 x0)))     (VitaCLIP_text_encoder.py:81-85)
-        hip.load().gava_convert_h16(hip.ptr(dX), hip.ptr(dx16), dX.numel(), BWD, hip.stream_ptr())
         hip.gemm(dx16, P["w_out_t"], None, dmix, epilogue=hip.EPI_H16, prec=BWD)
         hip.attention_backward(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], dmix, dqkv[:, :W], dqkv[:, W:2 * W], dqkv[:, 2 * W:],
                                batch=n, heads=H, n=L, prec=BWD, causal=True, q_scale=0.125)
         hip.gemm(dqkv, P["w_qkv_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)
-        hip.layernorm_backward(X0, P["ln1_g"], dxn, dX, accumulate=True)
+        hip.layernorm_backward(X0, P["ln1_g"], dxn, dX, accumulate=True, dx16=dx16)
     # x0 = [SOS | ctx[c] | suffix] + positional_embedding  (VitaCLIP_text_encoder.py:323-332,157): ctx rows 1..n_ctx
     return dX.view(n, L, W)[:, 1:1 + n_ctx].clone()
 
@@ -220,6 +219,7 @@ def vision_backward(model, saved, dcls_x, B, T):
     xn, qkv, mix, pre = new(R, D), new(R, 3 * D), new(R, D), new(R, F)
     X1, dx16, dhid, dmix, dqkv = new(R, D, dtype=torch.float32), new(R, D), new(R, F), new(R, D), new(R, 3 * D)
     dxn = new(R, D, dtype=torch.float32)
+    conv(dX, dx16)
     dgp = torch.zeros_like(v.global_prompts, dtype=torch.float32)
     for i in reversed(range(NL)):
         P, blk, X0 = bw["layers"][i], v.blocks[i], saved[1 + i]
@@ -255,13 +255,11 @@ def vision_backward(model, saved, dcls_x, B, T):
         hip.layernorm(X1, ln2_g, ln2_b, out16=xn, prec=BWD)
         hip.gemm(xn, P["w_fc1"], P["b_fc1"], pre, epilogue=hip.EPI_H16, prec=BWD)
         # ---- MLP'                                                           (vision_encoder_utils.py:109-115,199)
-        conv(dX, dx16)
-        hip.gemm(dx16, P["w_fc2_t"], None, dhid, epilogue=hip.EPI_H16, prec=BWD)
-        hip.qgelu_backward(pre, dhid, dhid, BWD)
+        #      (dx16 = bf16 copy of dX, written by the LayerNorm' that produced dX)
+        hip.gemm(dx16, P["w_fc2_t"], None, dhid, epilogue=hip.EPI_H16_QGELU_BWD, prec=BWD, aux=pre)    # fc2^T, gelu' fused
         hip.gemm(dhid, P["w_fc1_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)
-        hip.layernorm_backward(X1, ln2_g, dxn, dX, accumulate=True)
+        hip.layernorm_backward(X1, ln2_g, dxn, dX, accumulate=True, dx16=dx16)
         # ---- attention'                                                     (vision_encoder_utils.py:61-81,190-191)
-        conv(dX, dx16)
         hip.gemm(dx16, P["w_out_t"], None, dmix, epilogue=hip.EPI_H16, prec=BWD)
         part = new(BT, G + T + 1, 2 * D, dtype=torch.float32)     # per-frame partials of the shared prompt rows
         dside = part.view(BT * (G + T + 1), 2 * D)
@@ -270,7 +268,8 @@ def vision_backward(model, saved, dcls_x, B, T):
                                side_k=SIDEKV[:, :D], side_v=SIDEKV[:, D:], dside_k=dside[:, :D], dside_v=dside[:, D:],
                                n_g=G, T=T, has_summary=True)
         hip.gemm(dqkv, P["w_qkv_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)
-        hip.layernorm_backward(X0, ln1_g, dxn, dX, accumulate=True)
+        # (norm1' of the main rows is applied at the end of the block, after the prompt path has added its share to
+        #  the CLS rows of dX: it also writes the bf16 copy of the finished dX for the next block)
         # ---- prompt rows': sum the partials over the frames that share a row (global: all; local: the T frames of the
         #      clip; summary: its own frame), then K/V projection^T, norm1', split into global / local / summary
         pv = part.view(B, T, G + T + 1, 2 * D)
@@ -307,6 +306,7 @@ def vision_backward(model, saved, dcls_x, B, T):
         dCLS = new(BT, D, dtype=torch.float32)
         hip.gemm(hip.convert_h16(dCP, BWD), P["w_cls_t"], None, dCLS, epilogue=hip.EPI_F32, prec=BWD)
         dX.view(BT, n1, D)[:, 0] += dCLS
+        hip.layernorm_backward(X0, ln1_g, dxn, dX, accumulate=True, dx16=dx16)
     grads["global_prompts"] = dgp
     # ---- ln_pre' and the temporal embedding (VitaCLIP_vision_encoder.py:86-100,108-113): time_embed[t] is added to
     #      every token of frame t

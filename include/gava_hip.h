@@ -38,6 +38,7 @@ extern "C" {
 #define GAVA_EPI_H16_QGELU 1  /* out16 = quickgelu(acc + bias), x*sigmoid(1.702x)              */
 #define GAVA_EPI_F32 2        /* out32 = acc + bias (+ resid32, may alias out32)               */
 #define GAVA_EPI_F32_PATCH 3  /* patch-embed: row remap + pos/time embedding (see below)       */
+#define GAVA_EPI_H16_QGELU_BWD 4 /* backward: out16 = acc * quickgelu'(aux16), aux = pre-activation [M][ldo] */
 
 typedef void* gava_stream_t;
 
@@ -74,6 +75,7 @@ typedef struct {
    * (ldo >= 3N) with lo = h16(v - hi): the A operand of a following GEMM whose weight is packed
    * [W_hi | W_hi | W_lo] (K' = 3K), i.e. A_hi W_hi + A_lo W_hi + A_hi W_lo in one pass. */
   int split_out;
+  const void* aux;                  /* EPI_H16_QGELU_BWD: h16 pre-activations, rows as out (ld = ldo) */
 } gava_gemm_args;
 int gava_gemm(const gava_gemm_args* a, gava_stream_t stream);
 
@@ -199,7 +201,8 @@ int gava_similarity_head(const float* video, const float* text, const float* log
 
 /* LayerNorm backward (torch.nn.functional.layer_norm, eps 1e-5): dx = rstd*(g - mean(g) - xhat*mean(g*xhat)),
  * g = dy*gamma.  x rows may be gathered (x_row_index) and dx rows scattered (dx_row_index); accumulate != 0 adds
- * into dx (the residual branch).  dgamma/dbeta (both or neither) are accumulated with atomics. */
+ * into dx (the residual branch).  dgamma/dbeta (both or neither) are accumulated with atomics.  dx16 (optional,
+ * not with dx_row_index): an h16 copy of the final dx rows, i.e. the A operand of the next dgrad GEMM. */
 typedef struct {
   const float* x; int64_t x_stride; const int32_t* x_row_index;
   const float* gamma;
@@ -207,6 +210,7 @@ typedef struct {
   float* dx; int64_t dx_stride; const int32_t* dx_row_index;
   float* dgamma; float* dbeta;
   int rows, D, accumulate;
+  void* dx16; int64_t dx16_stride; int prec;
 } gava_layernorm_bwd_args;
 int gava_layernorm_backward(const gava_layernorm_bwd_args* a, gava_stream_t stream);
 
