@@ -529,8 +529,8 @@ class VitaCLIP(nn.Module):
         if self.logit_bias is not None:
             logits = logits + self.logit_bias
         self.text_features = tf / tf.norm(dim=-1, keepdim=True)
-        self.last.update(video_features=vf.detach(), summary=summary)
-        return logits, None, None
+        self.last.update(video_features=vf.detach(), summary=summary.detach())
+        return logits
 
     # ---- forward ------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, memory=None, video_nte=None, desc_wise=False):
@@ -586,26 +586,27 @@ class VitaCLIP(nn.Module):
         # under autograd every rank keeps its own clips (the reference's DDP computes the loss on local logits)
         video = cls_x if cls_x.requires_grad else self._gather(cls_x)
         if torch.is_grad_enabled() and (text.requires_grad or video.requires_grad or self.logit_scale.requires_grad):
-            if (self.add_nte and video_nte is not None) or (self.use_support_memory and memory is not None):
-                raise NotImplementedError("auxiliary heads under autograd (SURVEY §8f row 4)")
-            return self._train_head(video, text, summary, desc_wise)
-        Bg, Cn = video.shape[0], text.shape[0]
-        logits = torch.empty(Bg, Cn, dtype=torch.float32, device=x.device)
-        tfeat = torch.empty(Cn, sh["E"], dtype=torch.float32, device=x.device)
-        vnorm = torch.empty(Bg, sh["E"], dtype=torch.float32, device=x.device)
-        ls = self.logit_scale.detach().float().reshape(1)
-        lb = self.logit_bias.detach().float().reshape(1) if self.logit_bias is not None else None
-        hip.check(lib.gava_similarity_head(hip.ptr(video), hip.ptr(text), hip.ptr(ls), hip.ptr(lb), Bg, Cn, 1,
-                                           sh["E"], hip.ptr(logits), hip.ptr(tfeat), hip.ptr(vnorm), hip.stream_ptr()),
-                  "gava_similarity_head")
-        self.last.update(video_features=vnorm, summary=summary)
-        if self.use_text_prompt_learning:
-            self.text_features = tfeat            # VitaCLIP_model.py:293
-        if desc_wise and self.use_text_prompt_learning:
-            logits = [logits[:, i:i + 1] for i in range(Cn)]   # list of (B, n_kv=1), :265-276
+            # training: the 2*B*C*E-flop head is traced by torch so that d logits reaches both towers' HIP backward
+            logits = self._train_head(video, text, summary, desc_wise)
+        else:
+            Bg, Cn = video.shape[0], text.shape[0]
+            logits = torch.empty(Bg, Cn, dtype=torch.float32, device=x.device)
+            tfeat = torch.empty(Cn, sh["E"], dtype=torch.float32, device=x.device)
+            vnorm = torch.empty(Bg, sh["E"], dtype=torch.float32, device=x.device)
+            ls = self.logit_scale.detach().float().reshape(1)
+            lb = self.logit_bias.detach().float().reshape(1) if self.logit_bias is not None else None
+            hip.check(lib.gava_similarity_head(hip.ptr(video), hip.ptr(text), hip.ptr(ls), hip.ptr(lb), Bg, Cn, 1,
+                                               sh["E"], hip.ptr(logits), hip.ptr(tfeat), hip.ptr(vnorm), hip.stream_ptr()),
+                      "gava_similarity_head")
+            self.last.update(video_features=vnorm, summary=summary)
+            if self.use_text_prompt_learning:
+                self.text_features = tfeat            # VitaCLIP_model.py:293
+            if desc_wise and self.use_text_prompt_learning:
+                logits = [logits[:, i:i + 1] for i in range(Cn)]   # list of (B, n_kv=1), :265-276
 
-        # auxiliary heads: inactive at every accelerated configuration; kept as PyTorch glue on the
-        # device so that callers passing video_nte / memory still get the reference's outputs.
+        # auxiliary heads: inactive at every accelerated configuration; kept as PyTorch glue on the device so that
+        # callers passing video_nte / memory still get the reference's outputs - and, in training, its gradients
+        # (`summary` and `text_features` carry the towers' autograd nodes).
         if self.add_nte and video_nte is not None:              # VitaCLIP_model.py:311-345
             sp = self.sum_proj(summary)
             sp = sp / sp.norm(dim=-1, keepdim=True)

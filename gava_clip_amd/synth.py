@@ -109,6 +109,12 @@ def _rule(name: str, shape, cfg: VitaConfig):
             return "n", (2 * W) ** -0.5, 0.0
     if name == "prompt_learner.ctx":
         return "n", 0.02, 0.0
+    # auxiliary heads (VitaCLIP_model.py:148-199): sum_proj, tf_project.*, memory_project.*.*; their logit scales are
+    # kept small so that the log-softmax outputs of the synthetic case are not saturated
+    if name in ("logit_scale_vm", "logit_scale_mt"):
+        return "const", 0.0, 4.0
+    if name.startswith(("sum_proj.", "tf_project.", "memory_project.")) and leaf == "weight":
+        return "u", 1.0 / math.sqrt(shape[1]), 0.0
     raise KeyError(f"no synth rule for {name}")
 
 
@@ -127,6 +133,29 @@ def synth_state_dict(cfg: VitaConfig, n_cls: int, seed: int = 0):
     for name, shape in param_shapes(cfg, n_cls).items():
         out[name] = synth_param(name, shape, cfg, seed)
     return out
+
+
+def synth_aux_state(cfg: VitaConfig, n_cls: int, seed: int = 0):
+    """Parameters of the auxiliary heads (add_nte + use_support_memory), reference key order."""
+    from collections import OrderedDict
+    D, E = cfg.feature_dim, cfg.embed_dim
+    shapes = OrderedDict()
+    shapes["logit_scale_vm"] = ()
+    shapes["logit_scale_mt"] = ()
+    shapes["sum_proj.weight"], shapes["sum_proj.bias"] = (E, D), (E,)
+    mlp = [("0.weight", (E // 4, E)), ("0.bias", (E // 4,)), ("2.weight", (E // 8, E // 4)), ("2.bias", (E // 8,))]
+    for k, sh in mlp:
+        shapes["tf_project." + k] = sh
+    for c in range(n_cls):
+        for k, sh in mlp:
+            shapes[f"memory_project.{c}.{k}"] = sh
+    return OrderedDict((k, synth_param(k, sh, cfg, seed)) for k, sh in shapes.items())
+
+
+def synth_aux_inputs(B: int, E: int, n_mem: int = 5, seed: int = 1234):
+    """(video_nte (B, 70, E), memory (B, n_mem, E)) for the auxiliary heads."""
+    return (normalish("input.video_nte", (B, 70, E), seed).astype(np.float32),
+            normalish("input.memory", (B, n_mem, E), seed).astype(np.float32))
 
 
 def synth_clip(B: int, T: int, size: int, seed: int = 1234) -> np.ndarray:

@@ -13,8 +13,7 @@ fc GEMM - the forward kernels), then dgrad GEMMs on transposed weight copies + `
 `gava_layernorm_backward`, `gava_attention_backward`.  Gradient operands are bf16 (fp32 exponent range, so no
 loss scaling inside the library; the reference's fp16 autocast needs its GradScaler), accumulation fp32.
 
-The vision tower's backward (attention over 214 keys with shared prompt rows, MFMA work) is the next stage; until
-then video features enter the loss as constants, which is exactly CoOp text-prompt tuning on frozen video features.
+The second half of this module does the same for the vision tower (prompt parameters, summary path, time_embed).
 """
 import ctypes as C
 
@@ -193,8 +192,9 @@ def _wgrad(dy16, x16):
     return out
 
 
-def vision_backward(model, saved, dcls_x, B, T):
-    """d cls_x (B,E) -> {parameter name: gradient} for the trainable vision parameters."""
+def vision_backward(model, saved, dcls_x, B, T, dsummary=None):
+    """d cls_x (B,E) [+ d summary (B,D), the auxiliary NTE head's input] -> {parameter name: gradient} for the trainable
+    vision parameters."""
     sh = model._shape
     bw = model._pack_vision_backward()
     D, H, F, E, G, NL = sh["D"], sh["H"], sh["F"], sh["E"], sh["G"], sh["layers"]
@@ -281,6 +281,9 @@ def vision_backward(model, saved, dcls_x, B, T):
         hip.layernorm_backward(SIDE, ln1_g, dSIDEn, dSIDE)
         dgp[i] = dSIDE[:G]
         dlocal, dSUMM = dSIDE[G:G + BT], dSIDE[G + BT:]
+        if dsummary is not None and i == NL - 1:
+            # summary = mean over T of the last block's summary tokens (VitaCLIP_vision_encoder.py:129-130)
+            dSUMM = dSUMM + (dsummary.float() / T).repeat_interleave(T, dim=0)
         grads[f"blocks.{i}.local_prompts"] = dlocal.view(B, T, D).sum(0).unsqueeze(0)
         dCP = (dlocal + dSUMM).contiguous()                      # local = lp + CP;  SUMM = CP + out_proj(...)
         # ---- summary attention' (T tokens per clip) with parameter gradients
@@ -328,14 +331,15 @@ class VisionTowerFn(torch.autograd.Function):
         cls_x, summary = model.encode_video(x, saved=saved)
         fctx.model, fctx.BT = model, (B, T)
         fctx.save_for_backward(saved)
-        fctx.mark_non_differentiable(summary)
         return cls_x, summary
 
     @staticmethod
-    def backward(fctx, dcls_x, _dsummary):
+    def backward(fctx, dcls_x, dsummary):
         (saved,) = fctx.saved_tensors
         model = fctx.model
-        g = vision_backward(model, saved, dcls_x.contiguous(), *fctx.BT)
+        if dcls_x is None:
+            dcls_x = torch.zeros(fctx.BT[0], model._shape["E"], device=saved.device)
+        g = vision_backward(model, saved, dcls_x.contiguous(), *fctx.BT, dsummary=dsummary)
         out = []
         for name, p in _vision_trainables(model):
             gi = g.get(name)

@@ -239,3 +239,96 @@ def test_all_trainable_gradients_match_oracle_autograd(cfg, B):
     for n, p in m.named_parameters():
         if n not in ref:
             assert p.grad is None, n
+
+
+# ---- against the REFERENCE's own gradients (tools/gen_golden.py runs training/VitaCLIP_model.py under torch autograd
+#      in the build container and commits them as fixtures) -----------------------------------------------------------
+
+def _grad_sample(g, n=2048):
+    flat = g.reshape(-1)
+    step = max(1, flat.numel() // n)
+    return flat[::step][:n]
+
+
+def _check_against_reference_grads(m, gold, sampled=False):
+    got = {n: p.grad for n, p in m.named_parameters()}
+    names = [k.split(".", 1)[1] for k in gold.files if k.startswith("gradsub." if sampled else "grad.")]
+    assert len(names) > 20
+    worst = {}
+    for name in names:
+        g = got[name]
+        assert g is not None, name
+        if sampled:
+            ref_n, ref_s = float(gold["gradnorm." + name]), torch.from_numpy(gold["gradsub." + name])
+            gs = _grad_sample(g.float().cpu())
+            scale = ref_n if ref_n > 0 else 1.0
+            if name.endswith("k_proj.bias"):      # exactly zero in exact arithmetic (see the oracle test above)
+                q_n = float(gold["gradnorm." + name.replace("k_proj", "q_proj")])
+                assert float(g.norm()) <= 0.2 * q_n and ref_n <= 1e-4 * q_n
+                continue
+            worst[name] = max(abs(float(g.float().norm()) - ref_n) / scale,
+                              float((gs - ref_s).norm() / (ref_s.norm() + 1e-30)))
+        else:
+            ref = torch.from_numpy(gold["grad." + name])
+            assert g.shape == ref.shape, name
+            if name.endswith("k_proj.bias") and "summary" in name:
+                q_n = torch.from_numpy(gold["grad." + name.replace("k_proj", "q_proj")]).norm()
+                assert float(g.norm()) <= 0.2 * float(q_n) and float(ref.norm()) <= 1e-4 * float(q_n)
+                continue
+            worst[name] = rel(g.cpu(), ref)
+    bad = {k: v for k, v in worst.items() if v > 4e-2}
+    assert not bad, bad
+    for n, p in m.named_parameters():
+        if n not in names and not n.endswith("k_proj.bias"):
+            assert p.grad is None, n
+    return worst
+
+
+def test_gradients_match_reference_tiny(golden_dir):
+    import numpy as np, os
+    gold = np.load(os.path.join(golden_dir, "tiny_grads.npz"))
+    m = VitaCLIP(**model_kwargs(TINY, CLASSES_3))
+    m.load_state_dict(synth_torch_state(TINY, 3), strict=True)
+    m = m.cuda().train()
+    x = torch.from_numpy(synth.synth_clip(2, TINY.num_frames, TINY.input_size)).cuda()
+    logits, lmt, lvm = m(x)
+    assert lmt is None and lvm is None
+    assert (logits.detach().cpu() - torch.from_numpy(gold["logits"])).abs().max() <= 1e-3 * np.abs(gold["logits"]).max()
+    (logits * torch.from_numpy(gold["w_logits"]).cuda()).sum().backward()
+    _check_against_reference_grads(m, gold)
+
+
+def test_gradients_match_reference_with_auxiliary_heads(golden_dir):
+    """add_nte + use_support_memory (VitaCLIP_model.py:311-398): the NTE head hangs off `summary`, the memory head off
+    `text_features`; their outputs and every gradient (including sum_proj / tf_project / memory_project, handled by
+    torch, and the prompt parameters they reach THROUGH the HIP backward) against the reference."""
+    import numpy as np, os
+    gold = np.load(os.path.join(golden_dir, "tiny_aux_grads.npz"))
+    m = VitaCLIP(**model_kwargs(TINY, CLASSES_3), add_nte=True, use_support_memory=True, detach_features=False, num_classes=3)
+    sd = synth_torch_state(TINY, 3)
+    sd.update({k: torch.from_numpy(v) for k, v in synth.synth_aux_state(TINY, 3).items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    x = torch.from_numpy(synth.synth_clip(2, TINY.num_frames, TINY.input_size)).cuda()
+    nte, mem = synth.synth_aux_inputs(2, TINY.embed_dim)
+    logits, lmt, lvm = m(x, memory=torch.from_numpy(mem).cuda(), video_nte=torch.from_numpy(nte).cuda())
+    for got, key in ((logits, "logits"), (lvm, "logits_vm"), (lmt, "logits_mt")):
+        ref = torch.from_numpy(gold[key])
+        assert (got.detach().cpu() - ref).abs().max() <= 2e-3 * ref.abs().max(), key
+    loss = (logits * torch.from_numpy(gold["w_logits"]).cuda()).sum() + (lvm * torch.from_numpy(gold["w_vm"]).cuda()).sum() \
+        + (lmt * torch.from_numpy(gold["w_mt"]).cuda()).sum()
+    loss.backward()
+    _check_against_reference_grads(m, gold)
+
+
+def test_gradients_match_reference_vit_b16(golden_dir):
+    import numpy as np, os
+    gold = np.load(os.path.join(golden_dir, "b16_grads.npz"))
+    m = VitaCLIP(**model_kwargs(VIT_B16_T8, CLASSES_3))
+    m.load_state_dict(synth_torch_state(VIT_B16_T8, 3), strict=True)
+    m = m.cuda().train()
+    x = torch.from_numpy(synth.synth_clip(1, VIT_B16_T8.num_frames, VIT_B16_T8.input_size)).cuda()
+    logits = m(x)[0]
+    assert (logits.detach().cpu() - torch.from_numpy(gold["logits"])).abs().max() <= 1e-3 * np.abs(gold["logits"]).max()
+    (logits * torch.from_numpy(gold["w_logits"]).cuda()).sum().backward()
+    _check_against_reference_grads(m, gold, sampled=True)

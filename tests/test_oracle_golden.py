@@ -75,3 +75,28 @@ def test_oracle_c1_vit_b16(golden_dir):
     row7 = np.stack([r["trace"][f"block{i}"][:, 1 + 7].numpy() for i in range(12)])
     assert rel_to_max(row7, g["patch_row7"]) < TOL
     assert np.array_equal(r["logits"].argmax(-1).numpy(), g["logits"].argmax(-1))
+
+
+def test_oracle_gradients_match_reference_tiny(golden_dir):
+    """The oracle under torch autograd against the gradients the REFERENCE computed for the same loss
+    (tests/golden/tiny_grads.npz, tools/gen_golden.py run_grad_case): pins the checker of the HIP backward."""
+    g = np.load(os.path.join(golden_dir, "tiny_grads.npz"))
+    sd = synth_torch_state(TINY, 3)
+    p = {k: v.clone().float() for k, v in sd.items()}
+    names = [k[len("grad."):] for k in g.files if k.startswith("grad.")]
+    for k in names:
+        p[k].requires_grad_()
+    o = Oracle(TINY, p, torch.from_numpy(np.load(os.path.join(golden_dir, "tiny.npz"))["tokens"]))
+    x = torch.from_numpy(synth.synth_clip(2, TINY.num_frames, TINY.input_size))
+    vf, _ = o.vision(x)
+    tf = o.text(o.prompts())
+    logits = p["logit_scale"].exp() * (vf / vf.norm(dim=-1, keepdim=True)) @ (tf / tf.norm(dim=-1, keepdim=True)).t()
+    assert rel_to_max(logits.detach().numpy(), g["logits"]) < 1e-5
+    (logits * torch.from_numpy(g["w_logits"])).sum().backward()
+    for k in names:
+        ref = g["grad." + k]
+        got = p[k].grad.numpy()
+        if k.endswith("k_proj.bias"):          # exactly zero in exact arithmetic: both sides are rounding noise
+            assert np.abs(got).max() < 1e-6 and np.abs(ref).max() < 1e-6
+            continue
+        assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, k

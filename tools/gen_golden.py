@@ -8,7 +8,7 @@ lists) and ``video_dataset`` (only the constant NUM_COMB=70,
 gava_clip_amd/synth.py and are loaded with ``strict=True`` (which also pins state_dict key
 parity).  Outputs are data only: logits, features, per-layer CLS rows, token ids.
 
-    python tools/gen_golden.py            # writes tests/golden/{c1_b16,tiny}.npz, tokens_*.json
+    python tools/gen_golden.py            # writes tests/golden/{c1_b16,tiny}.npz, *_grads.npz, tokens_*.json
 """
 import json
 import os
@@ -43,7 +43,7 @@ def import_reference():
     return VitaCLIP_model, VitaCLIP_text_encoder
 
 
-def build_reference(mod, cfg, class_file):
+def build_reference(mod, cfg, class_file, **extra):
     model = mod.VitaCLIP(
         backbone_path="", input_size=(cfg.input_size, cfg.input_size), num_frames=cfg.num_frames,
         feature_dim=cfg.feature_dim, patch_size=(cfg.patch_size, cfg.patch_size),
@@ -54,14 +54,18 @@ def build_reference(mod, cfg, class_file):
         text_vocab_size=cfg.text_vocab_size, text_transformer_width=cfg.text_width,
         text_transformer_heads=cfg.text_heads, text_transformer_layers=cfg.text_layers,
         text_num_prompts=cfg.text_num_prompts, text_prompt_pos="end", text_prompt_init="",
-        text_prompt_CSC=True, text_prompt_classes_path=class_file)
+        text_prompt_CSC=True, text_prompt_classes_path=class_file, **extra)
     return model
 
 
-def load_synth(model, cfg, n_cls, seed=0):
+def load_synth(model, cfg, n_cls, seed=0, aux=False):
     sd = synth.synth_state_dict(cfg, n_cls, seed)
+    if aux:
+        sd.update(synth.synth_aux_state(cfg, n_cls, seed))
     ref_keys = list(model.state_dict().keys())
-    assert ref_keys == list(sd.keys()), "state_dict key order/name mismatch with reference"
+    assert sorted(ref_keys) == sorted(sd.keys()), "state_dict key mismatch with reference"
+    if not aux:
+        assert ref_keys == list(sd.keys()), "state_dict key order/name mismatch with reference"
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     # TextPromptLearner caches token embeddings at construction (text_encoder.py:284,296-300):
     # rebuild them from the loaded embedding table exactly as its __init__ does.
@@ -115,6 +119,56 @@ def run_case(mod, cfg, class_file, B, name, full_trace):
     return out
 
 
+def grad_sample(g, n=2048):
+    """Small fixture of a large gradient: its norm and a strided sample of <= n entries (same rule in the tests)."""
+    flat = g.reshape(-1)
+    step = max(1, flat.numel() // n)
+    return float(flat.double().norm()), flat[::step][:n].clone()
+
+
+def run_grad_case(mod, cfg, class_file, B, name, aux, sampled=False):
+    """The REFERENCE in train mode under torch autograd (training/train.py:441-470): gradients of every parameter it
+    leaves trainable, for loss = sum(w * logits) (+ the auxiliary heads' outputs when aux).  Pins the HIP backward."""
+    from gava_clip_amd.tokenizer import read_class_names
+    n_cls = len(read_class_names(class_file))
+    extra = dict(add_nte=True, use_support_memory=True, detach_features=False, num_classes=n_cls) if aux else {}
+    model = build_reference(mod, cfg, class_file, **extra)
+    load_synth(model, cfg, n_cls, aux=aux)
+    model.train()
+    x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size, seed=1234))
+    g = torch.Generator().manual_seed(2024)
+    w1 = torch.randn(B, n_cls, generator=g)
+    kw = {}
+    if aux:
+        nte, mem = synth.synth_aux_inputs(B, cfg.embed_dim)
+        kw = dict(video_nte=torch.from_numpy(nte), memory=torch.from_numpy(mem))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        logits, lmt, lvm = model(x, **kw)
+    loss = (logits * w1).sum()
+    out = dict(logits=logits.detach().numpy(), w_logits=w1.numpy())
+    if aux:
+        w2, w3 = torch.randn(B, B, generator=g), torch.randn(B, n_cls, generator=g)
+        loss = loss + (lvm * w2).sum() + (lmt * w3).sum()
+        out.update(logits_vm=lvm.detach().numpy(), logits_mt=lmt.detach().numpy(), w_vm=w2.numpy(), w_mt=w3.numpy())
+    loss.backward()
+    n = 0
+    for pname, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None, pname
+            if sampled:
+                nrm, sub = grad_sample(p.grad)
+                out["gradnorm." + pname], out["gradsub." + pname] = np.array(nrm), sub.numpy()
+            else:
+                out["grad." + pname] = p.grad.numpy()
+            n += 1
+        else:
+            assert p.grad is None
+    path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, n, "gradients")
+
+
 def dump_tokens(txt_mod):
     from gava_clip_amd.tokenizer import read_class_names, prompt_texts
     for fn in ("updrs_3cls_classes.txt", "k400_classes.txt"):
@@ -133,3 +187,6 @@ if __name__ == "__main__":
     dump_tokens(txt_mod)
     run_case(mod, TINY, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "tiny", True)
     run_case(mod, VIT_B16_T8, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "c1_b16", False)
+    run_grad_case(mod, TINY, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "tiny_grads", False)
+    run_grad_case(mod, TINY, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "tiny_aux_grads", True)
+    run_grad_case(mod, VIT_B16_T8, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 1, "b16_grads", False, sampled=True)
