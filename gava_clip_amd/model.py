@@ -158,34 +158,120 @@ class CLIPTextEncoder(_Params):
         nn.init.normal_(self.text_projection, std=transformer_width ** -0.5)
 
 
-class TextPromptLearner(_Params):
-    """VitaCLIP_text_encoder.py:174-308, plain (non-KAPT) class-specific-context path."""
+class ContextualPromptLearner(nn.Module):
+    """Knowledge-aware prompts, training/kapt_head.py:24-214, in the configuration that works upstream and that the
+    reference's training scripts use (train_scripts/updrs_3cls_train_tulip.sh:31-36): `cntn_split_uni[_disc]`, one
+    bias-free two-layer MLP per class (768 -> W/4 -> W, zero-initialised, kapt_head.py:127-133,161) applied to the
+    class's KEPLER entity embeddings, one prompt per knowledge version (n_kv).  Reads the same files as upstream,
+    relative to the working directory: ./data/ke_<type>/EntityEmb_<kv>.npy, simQdesc_<kv>.txt (kapt_head.py:60,94-112).
+    This small module (n_cls * n_kv rows) is evaluated by torch; its output joins the context vectors that enter the
+    HIP text tower, and its gradients come back through TextTowerFn."""
 
-    def __init__(self, classnames, text_model, num_prompts, prompts_init="", CSC=False, ctx_pos="end", **_unused):
+    def __init__(self, use_cntn, cntn_split, uni_mlp, use_disc, emb_dim, out_dim, inp_dim=768, n_cls=4, n_tokens=16,
+                 cls_type="updrs", knowledge_version=("v0",), use_descriptor=False, token_wise_mlp=False):
         super().__init__()
-        if prompts_init != "":
-            raise NotImplementedError(
-                "knowledge-aware prompts (text_prompt_init != '') need the KEPLER files under ./data/ke_* "
-                "(/root/reference/training/kapt_head.py:60-61); not part of the accelerated path (DESIGN.md)")
-        if not CSC:
-            # upstream: a generic (n_ctx, dim) ctx is unsqueezed to (n_ctx,1,dim) and cannot be
-            # concatenated (text_encoder.py:317,325-332) -> only CSC=True works there either.
-            raise NotImplementedError("text_prompt_CSC=False is broken in the reference (SURVEY.md §7.5); use CSC=True")
+        if use_descriptor or token_wise_mlp:
+            raise NotImplementedError("KAPT: use_descriptor / token_wise_mlp variants are not built")
+        if not (use_cntn and cntn_split and uni_mlp):
+            # upstream: without `split` ke_v0_path is read before assignment (kapt_head.py:91), without `uni` a Python
+            # list is .expand()-ed (:187-191), without `cntn` a 2-D ctx is concatenated with 3-D prefixes (text_encoder.py:325)
+            raise NotImplementedError("KAPT: only text_prompt_init with cntn+split+uni (optionally disc) runs in the reference")
+        assert len(knowledge_version) > 0, "No knowledge is specified."
+        self.type = cls_type.lower().split("_")[0]
+        self.n_cls, self.n_tokens = n_cls, n_tokens
+        self.updrs_ke_dir = f"./data/ke_{self.type}"
+        assert os.path.isdir(self.updrs_ke_dir), f"{self.updrs_ke_dir} (KEPLER knowledge files) not found"
+        embeds = torch.empty(n_cls, 0, inp_dim)
+        cls_disc = [[] for _ in range(n_cls)]
+        for kv in knowledge_version:
+            ent = np.load(os.path.join(self.updrs_ke_dir, f"EntityEmb_{kv}.npy"), allow_pickle=False)[:n_cls]
+            embeds = torch.cat([embeds, torch.from_numpy(ent).float().unsqueeze(1)], dim=1)
+            if use_disc:
+                with open(os.path.join(self.updrs_ke_dir, f"simQdesc_{kv}.txt")) as f:
+                    lines = [ln.strip() for ln in f]
+                for idc in range(n_cls):
+                    cls_disc[idc].append(lines[idc])
+            else:
+                for idc in range(n_cls):
+                    cls_disc[idc].append("")
+        self.projector = nn.ModuleList([nn.Sequential(nn.Linear(inp_dim, emb_dim, bias=False), nn.ReLU(inplace=True),
+                                                      nn.Linear(emb_dim, out_dim, bias=False)) for _ in range(n_cls)])
+        for m in self.projector.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.zeros_(m.weight)
+        self.cntn_embeds = list(embeds)          # plain attribute like upstream (:166-167): n_cls x (n_kv, inp_dim)
+        self.cls_disc = cls_disc
+
+    def forward(self, ctx_prompt):
+        """(n_cls, N, W) context parameters -> list of n_cls tensors (n_kv, N, W) (kapt_head.py:177-214)."""
+        prompts = []
+        for idc in range(self.n_cls):
+            e = self.cntn_embeds[idc] = self.cntn_embeds[idc].to(ctx_prompt.device)
+            emb = self.projector[idc](e).unsqueeze(1).expand(-1, self.n_tokens, -1)
+            prompts.append(ctx_prompt[idc].unsqueeze(0) + emb)
+        return prompts
+
+
+class TextPromptLearner(_Params):
+    """VitaCLIP_text_encoder.py:174-332: class-specific context vectors, plain ("X X ... name.") or knowledge-aware."""
+
+    def __init__(self, classnames, text_model, num_prompts, prompts_init="", CSC=False, ctx_pos="end", cls_type="updrs",
+                 knowledge_version=("v0",), use_descriptor=False, token_wise_mlp=False):
+        super().__init__()
+        ctx_init = prompts_init.lower()
+        assert ctx_init == "" or set(ctx_init.split("_")).issubset({"split", "uni", "cntn", "disc"}), "Invalid prompt initialization"
         if ctx_pos != "end":
             raise NotImplementedError(f"Unsupported class token position: {ctx_pos}")
         n_cls, n_ctx = len(classnames), num_prompts
         ctx_dim = text_model.ln_final.weight.shape[0]
-        ctx = torch.empty(n_cls, n_ctx, ctx_dim)
-        nn.init.normal_(ctx, std=0.02)
-        self.ctx = nn.Parameter(ctx)
-        texts = prompt_texts(classnames, n_ctx)
-        # list of (n_kv=1, 77) int tensors, one per class, like upstream (:266-270)
-        self.tokenized_prompts = [torch.from_numpy(tokenize(t, text_model.context_length)) for t in texts]
+        self.knowledge_aware_prompt = ctx_init != ""
+        names = [name.replace("_", " ") for name in classnames]
+        if self.knowledge_aware_prompt:
+            flags = set(ctx_init.split("_"))
+            self.context_prompt_learner = ContextualPromptLearner(
+                use_cntn="cntn" in flags, cntn_split="split" in flags, uni_mlp="uni" in flags, use_disc="disc" in flags,
+                emb_dim=ctx_dim // 4, out_dim=ctx_dim, n_cls=n_cls, n_tokens=n_ctx, cls_type=cls_type,
+                knowledge_version=list(knowledge_version), use_descriptor=use_descriptor, token_wise_mlp=token_wise_mlp)
+            self.ctx = nn.Parameter(torch.zeros(n_cls, n_ctx, ctx_dim))                      # :218-220
+            texts = [[self.context_prompt_learner.cls_disc[c][k] + " " + names[c] for k in range(len(knowledge_version))]
+                     for c in range(n_cls)]                                                  # :256-258
+        else:
+            if not CSC:
+                # upstream: a generic (n_ctx, dim) ctx is unsqueezed to (n_ctx,1,dim) and cannot be
+                # concatenated (text_encoder.py:317,325-332) -> only CSC=True works there either.
+                raise NotImplementedError("text_prompt_CSC=False is broken in the reference (SURVEY.md §7.5); use CSC=True")
+            ctx = torch.empty(n_cls, n_ctx, ctx_dim)
+            nn.init.normal_(ctx, std=0.02)
+            self.ctx = nn.Parameter(ctx)
+            texts = [[t] for t in prompt_texts(classnames, n_ctx)]
+        # list of (n_kv, 77) int tensors, one per class, like upstream (:266-270)
+        self.tokenized_prompts = [torch.from_numpy(np.concatenate([tokenize(t, text_model.context_length) for t in ts]))
+                                  for ts in texts]
         assert max(int((tp == 49407).nonzero()[:, -1].max()) for tp in self.tokenized_prompts) <= 77, \
             "The tokenized prompt is too long"
         self.n_cls, self.n_ctx = n_cls, n_ctx
+        self.n_kv = self.tokenized_prompts[0].shape[0]
+        assert all(tp.shape[0] == self.n_kv for tp in self.tokenized_prompts)
         self.class_token_position = ctx_pos
-        self.knowledge_aware_prompt = False
+
+    def embedding_token_ids(self):
+        """(n_cls*n_kv, L) token ids in the order their EMBEDDINGS sit in the prompt: [SOS | n_ctx context slots | rest].
+        Plain prompts carry "X" placeholders at the context slots, so this is the tokenised text itself (:300);
+        knowledge-aware prompts have no placeholders - upstream inserts the context after SOS and drops the last n_ctx
+        positions (`embedding[:, 1:-n_ctx]`, :298), i.e. every later token moves n_ctx places to the right.  The EOT
+        look-up keeps using the un-shifted ids (:169 with tokenized_prompts) - reproduced as is."""
+        tok = torch.cat(self.tokenized_prompts)
+        if not self.knowledge_aware_prompt:
+            return tok
+        eff = tok.clone()
+        eff[:, 1 + self.n_ctx:] = tok[:, 1:tok.shape[1] - self.n_ctx]
+        return eff
+
+    def full_context(self):
+        """(n_cls*n_kv, n_ctx, W) context rows of every prompt (text_encoder.py:310-317)."""
+        if self.knowledge_aware_prompt:
+            return torch.cat(self.context_prompt_learner(self.ctx), dim=0)
+        return self.ctx
 
 
 # ---------------------------------------------------------------------------------------------
@@ -292,7 +378,9 @@ class VitaCLIP(nn.Module):
             classes = read_class_names(text_prompt_classes_path)
             self.prompt_learner = TextPromptLearner(classnames=classes, text_model=self.textual,
                                                     num_prompts=text_num_prompts, prompts_init=text_prompt_init,
-                                                    CSC=text_prompt_CSC, ctx_pos=text_prompt_pos)
+                                                    CSC=text_prompt_CSC, ctx_pos=text_prompt_pos, cls_type=cls_type,
+                                                    knowledge_version=knowledge_version, use_descriptor=use_descriptor,
+                                                    token_wise_mlp=token_wise_mlp)
             self.tokenized_prompts = self.prompt_learner.tokenized_prompts
 
         # freeze (VitaCLIP_model.py:222-239)
@@ -331,8 +419,9 @@ class VitaCLIP(nn.Module):
         self.prec = hip.PREC_NAMES[name]
         self._packed = None
 
-    _PASS_THROUGH = ("prompt_learner.ctx", "logit_scale", "global_prompts", "local_prompts", "token_embedding",
-                     "pos_embed", "time_embed", "positional_embedding", "cls_token")
+    _PASS_THROUGH = ("prompt_learner.", "logit_scale", "global_prompts", "local_prompts", "token_embedding",
+                     "pos_embed", "time_embed", "positional_embedding", "cls_token", "sum_proj", "tf_project",
+                     "memory_project")
 
     def _pack_key(self):
         """Changes when a packed 16-bit copy goes stale.  fp32 pass-through parameters (prompts, embeddings, LN
@@ -418,10 +507,11 @@ class VitaCLIP(nn.Module):
                 L.ln1_g, L.ln1_b = K(self._f32(blk.ln_1.weight)), K(self._f32(blk.ln_1.bias))
                 L.ln2_g, L.ln2_b = K(self._f32(blk.ln_2.weight)), K(self._f32(blk.ln_2.bias))
             dev = t.token_embedding.weight.device
-            tok = torch.cat(self.tokenized_prompts).to(device=dev, dtype=torch.int32).contiguous()
-            eot_col = (tok == t.vocab_size - 1).nonzero()[:, -1]
-            assert eot_col.numel() == tok.shape[0], "every prompt must contain exactly one EOT token"
-            eot = (torch.arange(tok.shape[0], device=dev) * sh["L"] + eot_col).to(torch.int32).contiguous()
+            tok0 = torch.cat(self.tokenized_prompts).to(device=dev)
+            eot_col = (tok0 == t.vocab_size - 1).nonzero()[:, -1]
+            assert eot_col.numel() == tok0.shape[0], "every prompt must contain exactly one EOT token"
+            eot = (torch.arange(tok0.shape[0], device=dev) * sh["L"] + eot_col).to(torch.int32).contiguous()
+            tok = self.prompt_learner.embedding_token_ids().to(device=dev, dtype=torch.int32).contiguous()
             packed.update(txt=dict(token_embedding=K(self._f32(t.token_embedding.weight)),
                                    positional_embedding=K(self._f32(t.positional_embedding)),
                                    lnf_g=K(self._f32(t.ln_final.weight)), lnf_b=K(self._f32(t.ln_final.bias)),
@@ -492,7 +582,7 @@ class VitaCLIP(nn.Module):
         if nbytes == 0:
             raise hip.GavaError(f"unsupported text shape: {sh}")
         ws = self._workspace("text", nbytes, tok.device)
-        ctx = self.prompt_learner.ctx.detach().float().contiguous()
+        ctx = self.prompt_learner.full_context().detach().float().contiguous()
         out = torch.empty(n, sh["E"], dtype=torch.float32, device=tok.device)
         hip.check(lib.gava_text_forward(C.byref(m), hip.ptr(tok), hip.ptr(ctx), hip.ptr(pk["eot"]), hip.ptr(out),
                                         hip.ptr(ws), ws.numel(), hip.stream_ptr()), "gava_text_forward")
@@ -526,6 +616,10 @@ class VitaCLIP(nn.Module):
         vf = video / video.norm(dim=-1, keepdim=True)
         tf = text / text.norm(dim=-1, keepdim=True)
         logits = self.logit_scale.exp() * vf @ tf.t()
+        n_kv = self.prompt_learner.n_kv if self.use_text_prompt_learning else 1
+        if n_kv > 1:                                   # VitaCLIP_model.py:288-290
+            logits = logits.view(logits.shape[0], -1, n_kv).mean(-1)
+            tf = tf.view(-1, n_kv, tf.shape[-1]).mean(1)
         if self.logit_bias is not None:
             logits = logits + self.logit_bias
         self.text_features = tf / tf.norm(dim=-1, keepdim=True)
@@ -546,13 +640,15 @@ class VitaCLIP(nn.Module):
             if desc_wise:
                 assert self.training == False
             # the cached text features depend on the packed weights AND on the (pass-through) context vectors
-            key = ((self._pack_key(), self.prompt_learner.ctx._version, self.prompt_learner.ctx.data_ptr())
+            pl_params = list(self.prompt_learner.parameters())
+            key = ((self._pack_key(), tuple(q._version for q in pl_params), tuple(q.data_ptr() for q in pl_params))
                    if (self.cache_text_features and not self.training) else None)
-            train_text = torch.is_grad_enabled() and self.prompt_learner.ctx.requires_grad
+            train_text = torch.is_grad_enabled() and any(q.requires_grad for q in pl_params)
             if train_text:
-                # differentiable text tower (gava_clip_amd/training.py): HIP kernels in both directions
+                # differentiable text tower (gava_clip_amd/training.py): HIP kernels in both directions; the
+                # knowledge-aware context MLP (if any) is torch glue in front of it
                 from .training import TextTowerFn
-                text = TextTowerFn.apply(self, self.prompt_learner.ctx)
+                text = TextTowerFn.apply(self, self.prompt_learner.full_context())
             elif key is not None and self._text_cache is not None and self._text_cache[0] == key:
                 text = self._text_cache[1]
             else:
@@ -590,19 +686,29 @@ class VitaCLIP(nn.Module):
             logits = self._train_head(video, text, summary, desc_wise)
         else:
             Bg, Cn = video.shape[0], text.shape[0]
+            n_kv = self.prompt_learner.n_kv if self.use_text_prompt_learning else 1
             logits = torch.empty(Bg, Cn, dtype=torch.float32, device=x.device)
             tfeat = torch.empty(Cn, sh["E"], dtype=torch.float32, device=x.device)
             vnorm = torch.empty(Bg, sh["E"], dtype=torch.float32, device=x.device)
             ls = self.logit_scale.detach().float().reshape(1)
-            lb = self.logit_bias.detach().float().reshape(1) if self.logit_bias is not None else None
+            lb = self.logit_bias.detach().float().reshape(1) if (self.logit_bias is not None and n_kv == 1) else None
             hip.check(lib.gava_similarity_head(hip.ptr(video), hip.ptr(text), hip.ptr(ls), hip.ptr(lb), Bg, Cn, 1,
                                                sh["E"], hip.ptr(logits), hip.ptr(tfeat), hip.ptr(vnorm), hip.stream_ptr()),
                       "gava_similarity_head")
             self.last.update(video_features=vnorm, summary=summary)
+            per_prompt = logits
+            if n_kv > 1:
+                # knowledge-aware prompts: n_kv prompts per class, class logit = mean over them, class feature = the
+                # re-normalised mean of the unit prompt features (VitaCLIP_model.py:288-291); (B, C*n_kv) -> (B, C) glue
+                logits = per_prompt.view(Bg, Cn // n_kv, n_kv).mean(-1)
+                if self.logit_bias is not None:
+                    logits = logits + self.logit_bias.detach()
+                tfeat = tfeat.view(Cn // n_kv, n_kv, sh["E"]).mean(1)
+                tfeat = tfeat / tfeat.norm(dim=-1, keepdim=True)
             if self.use_text_prompt_learning:
                 self.text_features = tfeat            # VitaCLIP_model.py:293
             if desc_wise and self.use_text_prompt_learning:
-                logits = [logits[:, i:i + 1] for i in range(Cn)]   # list of (B, n_kv=1), :265-276
+                logits = [per_prompt[:, i:i + n_kv] for i in range(0, Cn, n_kv)]   # list of (B, n_kv), :265-276
 
         # auxiliary heads: inactive at every accelerated configuration; kept as PyTorch glue on the device so that
         # callers passing video_nte / memory still get the reference's outputs - and, in training, its gradients

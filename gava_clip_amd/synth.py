@@ -115,6 +115,8 @@ def _rule(name: str, shape, cfg: VitaConfig):
         return "const", 0.0, 4.0
     if name.startswith(("sum_proj.", "tf_project.", "memory_project.")) and leaf == "weight":
         return "u", 1.0 / math.sqrt(shape[1]), 0.0
+    if "context_prompt_learner.projector." in name and leaf == "weight":   # zero-initialised upstream; non-zero here
+        return "u", 0.5 / math.sqrt(shape[1]), 0.0
     raise KeyError(f"no synth rule for {name}")
 
 
@@ -156,6 +158,38 @@ def synth_aux_inputs(B: int, E: int, n_mem: int = 5, seed: int = 1234):
     """(video_nte (B, 70, E), memory (B, n_mem, E)) for the auxiliary heads."""
     return (normalish("input.video_nte", (B, 70, E), seed).astype(np.float32),
             normalish("input.memory", (B, n_mem, E), seed).astype(np.float32))
+
+
+KAPT_DESCRIPTIONS = (   # synthetic stand-ins for ./data/ke_<type>/simQdesc_<kv>.txt (one line per class and version)
+    "a person walking with {} gait impairment", "video of a patient whose walk shows {} signs",
+    "{} severity of slowness and reduced arm swing", "clinical gait recording rated {}", "footage of {} shuffling steps")
+
+
+def synth_knowledge_files(root: str, cls_type: str, n_cls: int, versions, seed: int = 0, inp_dim: int = 768):
+    """Write synthetic KEPLER knowledge files where training/kapt_head.py:60,94-112 looks for them:
+    <root>/data/ke_<type>/EntityEmb_<kv>.npy (n_cls, 768) and simQdesc_<kv>.txt (n_cls lines).  The real files are
+    not part of the reference repository; the same synthetic ones feed the reference (tools/gen_golden.py) and the tests."""
+    import os
+    d = os.path.join(root, "data", "ke_" + cls_type.lower().split("_")[0])
+    os.makedirs(d, exist_ok=True)
+    levels = ("no", "slight", "mild", "moderate", "severe", "very severe")
+    for i, kv in enumerate(versions):
+        np.save(os.path.join(d, f"EntityEmb_{kv}.npy"), normalish(f"kapt.entity.{kv}", (n_cls, inp_dim), seed).astype(np.float32))
+        with open(os.path.join(d, f"simQdesc_{kv}.txt"), "w") as f:
+            for c in range(n_cls):
+                f.write(KAPT_DESCRIPTIONS[i % len(KAPT_DESCRIPTIONS)].format(levels[c % len(levels)]) + "\n")
+    return d
+
+
+def synth_kapt_state(cfg: VitaConfig, n_cls: int, seed: int = 0, inp_dim: int = 768):
+    from collections import OrderedDict
+    W = cfg.text_width
+    out = OrderedDict()
+    for c in range(n_cls):
+        for k, sh in (("0.weight", (W // 4, inp_dim)), ("2.weight", (W, W // 4))):
+            name = f"prompt_learner.context_prompt_learner.projector.{c}.{k}"
+            out[name] = synth_param(name, sh, cfg, seed)
+    return out
 
 
 def synth_clip(B: int, T: int, size: int, seed: int = 1234) -> np.ndarray:

@@ -332,3 +332,33 @@ def test_gradients_match_reference_vit_b16(golden_dir):
     assert (logits.detach().cpu() - torch.from_numpy(gold["logits"])).abs().max() <= 1e-3 * np.abs(gold["logits"]).max()
     (logits * torch.from_numpy(gold["w_logits"]).cuda()).sum().backward()
     _check_against_reference_grads(m, gold, sampled=True)
+
+
+def test_kapt_forward_and_gradients_match_reference(golden_dir, tmp_path, monkeypatch):
+    """Knowledge-aware prompts (training/kapt_head.py; `cntn_split_uni_disc`, 3 knowledge versions -> 3 prompts per
+    class) on synthetic knowledge files: eval logits (mean over the class's prompts), class text features,
+    per-description logits, and every train-mode gradient including the per-class context MLPs - against the fixture
+    the reference produced on the same files."""
+    import numpy as np, os
+    gold = np.load(os.path.join(golden_dir, "tiny_kapt.npz"))
+    synth.synth_knowledge_files(str(tmp_path), "updrs", 3, ["v1", "v2", "v3"])
+    monkeypatch.chdir(tmp_path)
+    m = VitaCLIP(**{**model_kwargs(TINY, CLASSES_3), "text_prompt_init": "cntn_split_uni_disc", "knowledge_version": ["v1", "v2", "v3"]})
+    sd = synth_torch_state(TINY, 3)
+    sd.update({k: torch.from_numpy(v) for k, v in synth.synth_kapt_state(TINY, 3).items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    x = torch.from_numpy(synth.synth_clip(2, TINY.num_frames, TINY.input_size)).cuda()
+    with torch.no_grad():
+        logits = m(x)[0]
+        tfeat = m.text_features.clone()
+        desc = m(x, desc_wise=True)[0]
+    for got, key in ((logits, "logits"), (tfeat, "text_features"), (torch.stack(desc), "desc_logits")):
+        ref = torch.from_numpy(gold[key])
+        assert got.shape == ref.shape, key
+        assert (got.cpu() - ref).abs().max() <= 1e-3 * ref.abs().max(), key
+    m.train()
+    lg = m(x)[0]
+    (lg * torch.from_numpy(gold["w_logits"]).cuda()).sum().backward()
+    worst = _check_against_reference_grads(m, gold)
+    assert any("context_prompt_learner.projector" in k for k in worst)

@@ -30,7 +30,9 @@ def test_ctypes_structs_match_header_sizes():
     from gava_clip_amd import hip
     names = {"gava_gemm_args": hip.GemmArgs, "gava_layernorm_args": hip.LayerNormArgs,
              "gava_attention_args": hip.AttentionArgs, "gava_vision_layer": hip.VisionLayer,
-             "gava_vision_model": hip.VisionModel, "gava_text_layer": hip.TextLayer, "gava_text_model": hip.TextModel}
+             "gava_vision_model": hip.VisionModel, "gava_text_layer": hip.TextLayer, "gava_text_model": hip.TextModel,
+             "gava_preprocess_args": hip.PreprocessArgs, "gava_layernorm_bwd_args": hip.LayerNormBwdArgs,
+             "gava_attention_bwd_args": hip.AttentionBwdArgs}
     src = '#include <stdio.h>\n#include "gava_hip.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
@@ -78,8 +80,37 @@ def test_broken_reference_configs_are_rejected():
         VitaCLIP(**{**kw, "use_global_prompts": False})
     with pytest.raises(NotImplementedError):
         VitaCLIP(**{**kw, "text_prompt_CSC": False})
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):          # KAPT without split/uni does not run upstream either
+        VitaCLIP(**{**kw, "text_prompt_init": "cntn_disc"})
+    with pytest.raises(AssertionError):               # knowledge files missing: same assertion as kapt_head.py:61
         VitaCLIP(**{**kw, "text_prompt_init": "cntn_split_uni_disc"})
+
+
+def test_kapt_prompt_construction_matches_reference(golden_dir, tmp_path, monkeypatch):
+    """Knowledge-aware prompts on the synthetic knowledge files the golden was generated with: token ids, state_dict
+    keys, the shifted embedding order and the context rows (ctx + per-class MLP of the entity embeddings)."""
+    import os
+    import torch
+    from gava_clip_amd import VitaCLIP, synth
+    g = np.load(os.path.join(golden_dir, "tiny_kapt.npz"))
+    synth.synth_knowledge_files(str(tmp_path), "updrs", 3, ["v1", "v2", "v3"])
+    monkeypatch.chdir(tmp_path)
+    m = VitaCLIP(**{**model_kwargs(TINY), "text_prompt_init": "cntn_split_uni_disc", "knowledge_version": ["v1", "v2", "v3"]})
+    pl = m.prompt_learner
+    assert pl.n_kv == 3 and np.array_equal(torch.cat(m.tokenized_prompts).numpy(), g["tokens"])
+    keys = [k for k in m.state_dict() if "context_prompt_learner" in k]
+    assert keys == list(synth.synth_kapt_state(TINY, 3).keys())
+    sd = {**{k: torch.from_numpy(v) for k, v in synth.synth_state_dict(TINY, 3).items()},
+          **{k: torch.from_numpy(v) for k, v in synth.synth_kapt_state(TINY, 3).items()}}
+    m.load_state_dict(sd, strict=True)
+    eff, tok = pl.embedding_token_ids(), torch.cat(pl.tokenized_prompts)
+    n = TINY.text_num_prompts
+    assert torch.equal(eff[:, 0], tok[:, 0]) and torch.equal(eff[:, 1 + n:], tok[:, 1:-n])
+    full = pl.full_context()
+    assert full.shape == (9, n, TINY.text_width)
+    e = pl.context_prompt_learner.cntn_embeds[1]
+    want = pl.ctx[1].unsqueeze(0) + pl.context_prompt_learner.projector[1](e).unsqueeze(1)
+    assert torch.allclose(full[3:6], want.expand(-1, n, -1))
 
 
 def test_flop_model_matches_survey():

@@ -44,7 +44,7 @@ def import_reference():
 
 
 def build_reference(mod, cfg, class_file, **extra):
-    model = mod.VitaCLIP(
+    kw = dict(
         backbone_path="", input_size=(cfg.input_size, cfg.input_size), num_frames=cfg.num_frames,
         feature_dim=cfg.feature_dim, patch_size=(cfg.patch_size, cfg.patch_size),
         num_heads=cfg.num_heads, num_layers=cfg.num_layers, mlp_factor=cfg.mlp_factor,
@@ -54,17 +54,20 @@ def build_reference(mod, cfg, class_file, **extra):
         text_vocab_size=cfg.text_vocab_size, text_transformer_width=cfg.text_width,
         text_transformer_heads=cfg.text_heads, text_transformer_layers=cfg.text_layers,
         text_num_prompts=cfg.text_num_prompts, text_prompt_pos="end", text_prompt_init="",
-        text_prompt_CSC=True, text_prompt_classes_path=class_file, **extra)
-    return model
+        text_prompt_CSC=True, text_prompt_classes_path=class_file)
+    kw.update(extra)
+    return mod.VitaCLIP(**kw)
 
 
-def load_synth(model, cfg, n_cls, seed=0, aux=False):
+def load_synth(model, cfg, n_cls, seed=0, aux=False, kapt=False):
     sd = synth.synth_state_dict(cfg, n_cls, seed)
     if aux:
         sd.update(synth.synth_aux_state(cfg, n_cls, seed))
+    if kapt:
+        sd.update(synth.synth_kapt_state(cfg, n_cls, seed))
     ref_keys = list(model.state_dict().keys())
     assert sorted(ref_keys) == sorted(sd.keys()), "state_dict key mismatch with reference"
-    if not aux:
+    if not aux and not kapt:
         assert ref_keys == list(sd.keys()), "state_dict key order/name mismatch with reference"
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     # TextPromptLearner caches token embeddings at construction (text_encoder.py:284,296-300):
@@ -74,7 +77,7 @@ def load_synth(model, cfg, n_cls, seed=0, aux=False):
         for idc in range(pl.n_cls):
             emb = model.textual.token_embedding(pl.tokenized_prompts[idc])
             pl.token_prefix[idc] = emb[:, :1, :]
-            pl.token_suffix[idc] = emb[:, 1 + pl.n_ctx:, :]
+            pl.token_suffix[idc] = emb[:, 1: -pl.n_ctx, :] if pl.knowledge_aware_prompt else emb[:, 1 + pl.n_ctx:, :]
     return sd
 
 
@@ -169,6 +172,52 @@ def run_grad_case(mod, cfg, class_file, B, name, aux, sampled=False):
     print("wrote", path, n, "gradients")
 
 
+KAPT_VERSIONS = ["v1", "v2", "v3"]
+
+
+def run_kapt_case(mod, cfg, class_file, B, name):
+    """Knowledge-aware prompts (training/kapt_head.py, text_prompt_init='cntn_split_uni_disc', the configuration of
+    train_scripts/updrs_3cls_train_tulip.sh) on SYNTHETIC knowledge files (the real ./data/ke_* are not distributed):
+    eval logits / text features / per-description logits, and train-mode gradients incl. the context MLPs."""
+    import tempfile
+    from gava_clip_amd.tokenizer import read_class_names
+    n_cls = len(read_class_names(class_file))
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        synth.synth_knowledge_files(tmp, "updrs", n_cls, KAPT_VERSIONS)
+        os.chdir(tmp)
+        try:
+            model = build_reference(mod, cfg, class_file, text_prompt_init="cntn_split_uni_disc",
+                                    knowledge_version=list(KAPT_VERSIONS), cls_type="updrs")
+        finally:
+            os.chdir(cwd)
+    load_synth(model, cfg, n_cls, kapt=True)
+    x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size, seed=1234))
+    model.eval()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        logits, _, _ = model(x)
+        tfeat = model.text_features.clone()
+        desc, _, _ = model(x, desc_wise=True)
+    out = dict(logits=logits.numpy(), text_features=tfeat.numpy(), desc_logits=np.stack([d.numpy() for d in desc]),
+               tokens=torch.cat(model.tokenized_prompts).numpy().astype(np.int32))
+    model.train()
+    w1 = torch.randn(B, n_cls, generator=torch.Generator().manual_seed(2024))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lg = model(x)[0]
+    (lg * w1).sum().backward()
+    out["w_logits"] = w1.numpy()
+    n = 0
+    for pname, p in model.named_parameters():
+        if p.requires_grad:
+            out["grad." + pname] = p.grad.numpy()
+            n += 1
+    path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, n, "gradients", out["logits"].shape, out["desc_logits"].shape)
+
+
 def dump_tokens(txt_mod):
     from gava_clip_amd.tokenizer import read_class_names, prompt_texts
     for fn in ("updrs_3cls_classes.txt", "k400_classes.txt"):
@@ -190,3 +239,4 @@ if __name__ == "__main__":
     run_grad_case(mod, TINY, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "tiny_grads", False)
     run_grad_case(mod, TINY, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "tiny_aux_grads", True)
     run_grad_case(mod, VIT_B16_T8, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 1, "b16_grads", False, sampled=True)
+    run_kapt_case(mod, TINY, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "tiny_kapt")
