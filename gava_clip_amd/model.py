@@ -430,16 +430,38 @@ class VitaCLIP(nn.Module):
         ver, addr = 0, 0
         for name, p in self.named_parameters():
             addr ^= p.data_ptr()
-            if p.dim() >= 2 and not any(k in name for k in self._PASS_THROUGH):
+            if p.dim() >= 2 and not p.requires_grad and not any(k in name for k in self._PASS_THROUGH):
                 ver += p._version
         ps = next(self.parameters())
         return (self.prec, self.text_split_precision, ps.device, addr, ver)
+
+    def _summary_weight_versions(self):
+        """Versions of the only TRAINABLE weights that have 16-bit copies (summary_attn_layer projections): an optimizer
+        step refreshes just those copies in place (same device pointers) instead of re-converting every frozen weight."""
+        return [tuple(w._version for w in (b.summary_attn_layer.q_proj.weight, b.summary_attn_layer.k_proj.weight,
+                                           b.summary_attn_layer.v_proj.weight, b.summary_attn_layer.out_proj.weight,
+                                           b.summary_attn_layer.q_proj.bias, b.summary_attn_layer.k_proj.bias,
+                                           b.summary_attn_layer.v_proj.bias))
+                for b in self.visual.blocks]
+
+    def _refresh_summary_weights(self, packed):
+        cur = self._summary_weight_versions()
+        if cur == packed["summary_ver"]:
+            return
+        for i, blk in enumerate(self.visual.blocks):
+            if cur[i] != packed["summary_ver"][i]:
+                s_ = blk.summary_attn_layer
+                packed["w_sqkv"][i].copy_(self._h16(torch.cat([s_.q_proj.weight, s_.k_proj.weight, s_.v_proj.weight], 0)))
+                packed["w_sout"][i].copy_(self._h16(s_.out_proj.weight))
+                packed["b_sqkv"][i].copy_(torch.cat([s_.q_proj.bias, s_.k_proj.bias, s_.v_proj.bias], 0).detach().float())
+        packed["summary_ver"] = cur
 
     def _pack_vision_backward(self):
         from . import training
         key = self._pack_key()
         if getattr(self, "_bwd_pack_v", None) is None or self._bwd_pack_v[0] != key:
             self._bwd_pack_v = (key, training.pack_vision_backward(self))
+        training.refresh_vision_backward(self, self._bwd_pack_v[1])
         return self._bwd_pack_v[1]
 
     def _pack_text_backward(self):
@@ -458,9 +480,11 @@ class VitaCLIP(nn.Module):
     def _pack(self):
         key = self._pack_key()
         if self._packed is not None and self._packed_key == key:
+            self._refresh_summary_weights(self._packed)
             return self._packed
         sh, v = self._shape, self.visual
         keep = []  # tensors referenced by raw pointers in the structs
+        w_sqkv_t, w_sout_t, b_sqkv_t = [], [], []
 
         def K(t):
             keep.append(t)
@@ -488,12 +512,16 @@ class VitaCLIP(nn.Module):
             L.ln2_g, L.ln2_b = K(self._f32(blk.norm2.weight)), K(self._f32(blk.norm2.bias))
             L.w_cls, L.b_cls = K(self._h16(blk.cls_proj.weight)), K(self._f32(blk.cls_proj.bias))
             L.sln_g, L.sln_b = K(self._f32(blk.summary_ln.weight)), K(self._f32(blk.summary_ln.bias))
-            L.w_sqkv = K(self._h16(torch.cat([s.q_proj.weight, s.k_proj.weight, s.v_proj.weight], 0)))
-            L.b_sqkv = K(self._f32(torch.cat([s.q_proj.bias, s.k_proj.bias, s.v_proj.bias], 0)))
-            L.w_sout, L.b_sout = K(self._h16(s.out_proj.weight)), K(self._f32(s.out_proj.bias))
+            w_sqkv_t.append(self._h16(torch.cat([s.q_proj.weight, s.k_proj.weight, s.v_proj.weight], 0)))
+            w_sout_t.append(self._h16(s.out_proj.weight))
+            L.w_sqkv, L.w_sout = K(w_sqkv_t[-1]), K(w_sout_t[-1])
+            b_sqkv_t.append(self._f32(torch.cat([s.q_proj.bias, s.k_proj.bias, s.v_proj.bias], 0)))
+            L.b_sqkv = K(b_sqkv_t[-1])
+            L.b_sout = K(self._f32(s.out_proj.bias))
             L.local_prompts = K(self._f32(blk.local_prompts[0]))
             L.global_prompts = K(self._f32(v.global_prompts[i]))
-        packed = dict(vis=vis, vis_layers=layers, keep=keep)
+        packed = dict(vis=vis, vis_layers=layers, keep=keep, w_sqkv=w_sqkv_t, w_sout=w_sout_t, b_sqkv=b_sqkv_t,
+                      summary_ver=self._summary_weight_versions())
         if self.use_text_prompt_learning:
             t = self.textual
             tlayers = (hip.TextLayer * sh["TL"])()

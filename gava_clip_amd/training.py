@@ -174,7 +174,24 @@ def pack_vision_backward(model):
             w_cls=_bf16(blk.cls_proj.weight), w_cls_t=_bf16(blk.cls_proj.weight.detach().t()), b_cls=f32(blk.cls_proj.bias),
             w_sqkv=_bf16(wsqkv), w_sqkv_t=_bf16(wsqkv.t()),
             w_sout=_bf16(s.out_proj.weight), w_sout_t=_bf16(s.out_proj.weight.detach().t())))
-    return dict(layers=layers, proj=_bf16(v.proj))    # cls_x = ln_post(x) @ proj (D,E): dx = d @ proj^T = gemm(d, W=proj)
+    return dict(layers=layers, proj=_bf16(v.proj),     # cls_x = ln_post(x) @ proj (D,E): dx = d @ proj^T = gemm(d, W=proj)
+                summary_ver=model._summary_weight_versions())
+
+
+def refresh_vision_backward(model, bw):
+    """The summary-attention projections are the only trainable weights with bf16 copies: re-convert just those (in place)
+    after an optimizer step."""
+    cur = model._summary_weight_versions()
+    if cur == bw["summary_ver"]:
+        return
+    for i, blk in enumerate(model.visual.blocks):
+        if cur[i] != bw["summary_ver"][i]:
+            s = blk.summary_attn_layer
+            wsqkv = torch.cat([s.q_proj.weight, s.k_proj.weight, s.v_proj.weight], 0).detach()
+            P = bw["layers"][i]
+            P["w_sqkv"].copy_(_bf16(wsqkv)); P["w_sqkv_t"].copy_(_bf16(wsqkv.t()))
+            P["w_sout"].copy_(_bf16(s.out_proj.weight)); P["w_sout_t"].copy_(_bf16(s.out_proj.weight.detach().t()))
+    bw["summary_ver"] = cur
 
 
 def _pad_k(t, mult=64):
