@@ -676,7 +676,19 @@ class VitaCLIP(nn.Module):
                 # differentiable text tower (gava_clip_amd/training.py): HIP kernels in both directions; the
                 # knowledge-aware context MLP (if any) is torch glue in front of it
                 from .training import TextTowerFn
-                text = TextTowerFn.apply(self, self.prompt_learner.full_context())
+                ctx_full = self.prompt_learner.full_context()
+                if self.text_on_side_stream:
+                    # own stream, like the inference path; autograd runs TextTowerFn.backward on this stream too
+                    # (and inserts the cross-stream waits), so the text tower overlaps the vision tower both ways
+                    main = torch.cuda.current_stream(x.device)
+                    if self._text_stream is None or self._text_stream.device != x.device:
+                        self._text_stream = torch.cuda.Stream(device=x.device)
+                    text_stream = self._text_stream
+                    text_stream.wait_stream(main)
+                    with torch.cuda.stream(text_stream):
+                        text = TextTowerFn.apply(self, ctx_full)
+                else:
+                    text = TextTowerFn.apply(self, ctx_full)
             elif key is not None and self._text_cache is not None and self._text_cache[0] == key:
                 text = self._text_cache[1]
             else:
