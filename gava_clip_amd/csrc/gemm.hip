@@ -28,7 +28,6 @@ namespace {
 
 constexpr int BK = 64;
 // s_waitcnt immediate for "vmcnt(n) only" on gfx9/CDNA: vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14
-constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 
 struct GemmParams {
   const unsigned short* A; long lda;
@@ -904,297 +903,6 @@ void gemm256r_kernel(const GemmParams p) {
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// v5 "ping-pong" (EXPERIMENTAL, GAVA_GEMM_VARIANT=5): BK = 32 stages in a 4-slot ring (4 x 32 KiB,
-// 64-byte LDS rows, swizzle chunk ^ {0,3,2,1}[g], g = (row>>2)&3 for A and (row>>4)&3 for the
-// row-permuted W tile) with the two wave groups that share
-// each SIMD (waves 0-3 = rows 0-127, waves 4-7 = rows 128-255 of the tile) running half a stage
-// apart, enforced by two raw s_barriers per stage: while one group issues its 32 MFMAs the other
-// reads its 12 fragments from LDS and issues its 4 LDS-DMA pieces (which cost ~100 issue cycles
-// each beside a running matrix pipe), so the pipe always has exactly one feeder per SIMD.
-// Each wave confirms its OWN pieces one stage ahead (counted vmcnt), and a barrier always
-// separates that confirmation from the other group's reads.  Rows are 64 B in LDS; the swizzle is chunk ^ f(g), f = {0,3,2,1}, with
-// g = (row>>2)&3 for the A tile and (row>>4)&3 for the (row-permuted) W tile: conflict-free for
-// every ds_read_b128 lane group of both read patterns.
-template <class P, int EPI, bool RES, bool SPLIT>
-__global__ __launch_bounds__(512, 2)
-void gemm256pp_kernel(const GemmParams p) {
-  constexpr int BM = 256, BN = 256, NW = 8, BKS = 32, NSLOT = 4;
-  constexpr int A_BYTES = BM * BKS * 2, STAGE = (BM + BN) * BKS * 2;   // 16 KiB, 32 KiB
-  constexpr int PPW = (BM + BN) / 16 / NW;                             // 4 glds per wave per stage
-  constexpr int NSTORE = (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH) ? 32 : (SPLIT ? 48 : 16);
-  __shared__ __attribute__((aligned(16))) char smem[NSLOT * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int fr = lane & 15, fg = lane >> 4;
-
-  const int nwg = p.n_tiles, nb = gridDim.x;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = nb >> 3;
-  const int q = nwg >> 3, r = nwg & 7;
-  const int x_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int x_count = xcd < r ? q + 1 : q;
-  const int my_tiles = slot < x_count ? (x_count - slot + per_xcd - 1) / per_xcd : 0;
-  if (my_tiles == 0) return;
-  const int nk = p.K / BKS;
-  const int G = my_tiles * nk;
-
-  auto tile_coords = [&](int j, int& m0, int& n0) {
-    const int wg = x_first + slot + j * per_xcd;
-    const int per_group = p.sm * p.tiles_n;
-    const int g = wg / per_group, first_m = g * p.sm;
-    const int sm = min(p.sm, p.tiles_m - first_m);
-    const int w = wg - g * per_group;
-    const int chunk = w / (sm * p.sn), rr = w - chunk * (sm * p.sn);
-    m0 = (first_m + rr % sm) * BM;
-    n0 = (chunk * p.sn + rr / sm) * BN;
-  };
-  auto fswz = [](int g) { return (4 - g) & 3; };   // {0,3,2,1}
-
-  const unsigned short* src[PPW];
-  auto set_src = [&](int m0, int n0) {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int piece = wave + i * NW;                 // 0..15: A rows, 16..31: W rows (16 rows each)
-      const int row = (piece & 15) * 16 + (lane >> 2);
-      if (i < PPW / 2) {
-        const int chunk = (lane & 3) ^ fswz((row >> 2) & 3);
-        int gm = m0 + row;
-        gm = gm < p.M ? gm : p.M - 1;
-        src[i] = p.A + (long)gm * p.lda + chunk * 8;
-      } else {
-        const int chunk = (lane & 3) ^ fswz((row >> 4) & 3);
-        src[i] = p.W + (long)(n0 + row) * p.ldw + chunk * 8;
-      }
-    }
-  };
-  // Load cursor: the next stage to issue is (tile ld_j, k-step ld_kt) -> slot (issued & 3).  Past the
-  // last real stage the same 4 pieces are re-issued from valid addresses into a slot nobody reads
-  // (keeps the loop body branch-free and the vmcnt arithmetic constant); they are drained before exit.
-  int ld_kt = 0, ld_j = 0, issued = 0;
-  // `slot` is a compile-time constant at every call site: with dynamic ring indices hipcc cannot prove
-  // that an in-flight LDS-DMA does not alias the next ds_read and inserts s_waitcnt vmcnt(0) before it,
-  // which silently drains the whole ring every stage.
-  auto issue_piece = [&](int slot, int i) {
-    const int kt_eff = issued < G ? ld_kt : 0;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + (long)kt_eff * BKS),
-                                     LDS_PTR(void, smem + slot * STAGE + (wave + i * NW) * 1024), 16, 0, 0);
-  };
-  auto advance = [&]() {
-    if (issued < G && ++ld_kt == nk) {
-      ld_kt = 0;
-      ++ld_j;
-      if (ld_j < my_tiles) {
-        int mm, nn;
-        tile_coords(ld_j, mm, nn);
-        set_src(mm, nn);
-      }
-    }
-    ++issued;
-  };
-  auto issue_next = [&](int slot) {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) issue_piece(slot, i);
-    advance();
-  };
-
-  const int sw = fswz(fr >> 2);
-  const int a_off = (wr * 128 + fr) * 64 + ((fg ^ sw) << 4);
-  const int w_off = A_BYTES + (wc * 64 + 16 * (fr >> 2) + (fr & 3)) * 64 + ((fg ^ sw) << 4);
-
-  f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  int m0, n0;
-  tile_coords(0, m0, n0);
-  set_src(m0, n0);
-  issue_next(0); issue_next(1); issue_next(2);
-  // stage 0 must be visible to everyone before the first reads
-  __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * PPW));
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one segment behind group 0
-  unsigned long long tL = 0, tB1 = 0, tC = 0, tB2 = 0, tE = 0, ts = 0;
-  const bool stamp = p.dbg != nullptr;
-  if (stamp) ts = clock64();
-  int grace = 0;   // load segments during which this wave's NSTORE epilogue stores may stay in flight
-#ifndef GAVA_PP_GLDS_C
-#define GAVA_PP_GLDS_C 2   // LDS-DMA pieces (of 4 per stage) issued inside the MFMA segment
-#endif
-  constexpr int NC = GAVA_PP_GLDS_C, NL = PPW - NC;
-
-  // one 32-deep stage with compile-time ring slot S (host guarantees nk % 4 == 0, so slot = kt & 3)
-  auto stage_body = [&](auto S_, bool closing_barrier) {
-    constexpr int S = decltype(S_)::value;
-    // ---------------- load segment (the other group is in its MFMA segment)
-    // confirm my pieces of stage g+1; the 4 pieces of stage g+2 may stay in flight
-    // (the builtin, not inline asm: hipcc's wait-insertion pass must SEE these counted waits, or it
-    // assumes older LDS-DMAs may still be pending and adds its own vmcnt(0) before the ds_reads)
-    if (grace > 0) __builtin_amdgcn_s_waitcnt(vmcnt_imm(PPW + NSTORE));
-    else __builtin_amdgcn_s_waitcnt(vmcnt_imm(PPW));
-    if (grace > 0) --grace;
-    const char* cur = smem + S * STAGE;
-    s16x8_t wf[4], af[8];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) wf[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 256);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 1024);
-    // stage g+3 -> slot of stage g-1 (both groups finished reading it at least one barrier ago)
-#pragma unroll
-    for (int i = 0; i < NL; ++i) issue_piece((S + 3) & 3, i);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (stamp) { const unsigned long long t = clock64(); tL += t - ts; ts = t; }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (stamp) { const unsigned long long t = clock64(); tB1 += t - ts; ts = t; }
-    // ---------------- MFMA segment (the other group is in its load segment); the remaining pieces
-    // ride in the gaps between MFMAs
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = P::mfma(wf[jj], af[i], acc[i][jj]);
-      if (NC > 0 && (i & 1) == 1 && (i >> 1) < NC) issue_piece((S + 3) & 3, NL + (i >> 1));
-    }
-    if (NC > 0) {
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 32 - 8 * NC, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    advance();
-    if (stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t = clock64(); tC += t - ts; ts = t; }
-    if (closing_barrier) {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (stamp) { const unsigned long long t = clock64(); tB2 += t - ts; ts = t; }
-    }
-  };
-
-  for (int j = 0; j < my_tiles; ++j) {
-    // 12 stages per trip: hipcc still drains the ring (vmcnt(0)) once at the top of the loop body, where its
-    // wait-insertion pass merges the back edge conservatively; once per 12 stages is cheap.
-    for (int kt = 0; kt < nk; kt += 12) {
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        stage_body(std::integral_constant<int, 0>{}, true);
-        stage_body(std::integral_constant<int, 1>{}, true);
-        stage_body(std::integral_constant<int, 2>{}, true);
-        stage_body(std::integral_constant<int, 3>{}, u < 2 || kt + 12 < nk);   // the tile's last barrier follows the epilogue
-      }
-    }
-
-    // ---- epilogue of tile j (same register->output map as v3)
-    const int nb0 = n0 + wc * 64 + 16 * fg;
-    float4 bj[4];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-      bj[jj] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb0 + 4 * jj) : make_float4(0, 0, 0, 0);
-    const bool full = m0 + BM <= p.M;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wr * 128 + i * 16 + fr;
-      if (m < p.M && !(p.ablate & 4)) {
-        long orow = m;
-        const float* posr = nullptr;
-        const float* timr = nullptr;
-        if (EPI == GAVA_EPI_F32_PATCH) {
-          const int frame = m / p.n_patches, pp = m - frame * p.n_patches;
-          orow = (long)frame * (p.n_patches + 1) + 1 + pp;
-          posr = p.pos + (long)(1 + pp) * p.N + nb0;
-          timr = p.time + (long)(frame % p.T) * p.N + nb0;
-        }
-        float v[16];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          v[4 * jj + 0] = acc[i][jj][0] + bj[jj].x; v[4 * jj + 1] = acc[i][jj][1] + bj[jj].y;
-          v[4 * jj + 2] = acc[i][jj][2] + bj[jj].z; v[4 * jj + 3] = acc[i][jj][3] + bj[jj].w;
-        }
-        if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU) {
-          if (EPI == GAVA_EPI_H16) {
-            if (nb0 < p.scale_cols) {
-#pragma unroll
-              for (int e = 0; e < 16; ++e) v[e] *= p.scale;
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = quick_gelu(v[e]);
-          }
-          unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + nb0;
-          if (SPLIT) {
-            uint2 hi[4], lo[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) split4<P>(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3], hi[jj], lo[jj]);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const uint4 H = make_uint4(hi[2 * h].x, hi[2 * h].y, hi[2 * h + 1].x, hi[2 * h + 1].y);
-              const uint4 L = make_uint4(lo[2 * h].x, lo[2 * h].y, lo[2 * h + 1].x, lo[2 * h + 1].y);
-              *reinterpret_cast<uint4*>(o + 8 * h) = H;
-              *reinterpret_cast<uint4*>(o + p.N + 8 * h) = L;
-              *reinterpret_cast<uint4*>(o + 2 * p.N + 8 * h) = H;
-            }
-          } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const uint2 x = pack4<P>(v[8 * h], v[8 * h + 1], v[8 * h + 2], v[8 * h + 3]);
-              const uint2 y = pack4<P>(v[8 * h + 4], v[8 * h + 5], v[8 * h + 6], v[8 * h + 7]);
-              *reinterpret_cast<uint4*>(o + 8 * h) = make_uint4(x.x, x.y, y.x, y.y);
-            }
-          }
-        } else {
-          float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + nb0;
-          if (EPI == GAVA_EPI_F32 && RES) {
-            const float* rp = p.resid + orow * p.ldr + nb0;
-            float4 rr[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) rr[jj] = *reinterpret_cast<const float4*>(rp + 4 * jj);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              v[4 * jj] += rr[jj].x; v[4 * jj + 1] += rr[jj].y; v[4 * jj + 2] += rr[jj].z; v[4 * jj + 3] += rr[jj].w;
-            }
-          }
-          if (EPI == GAVA_EPI_F32_PATCH) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              const float4 pr = *reinterpret_cast<const float4*>(posr + 4 * jj);
-              const float4 tr = *reinterpret_cast<const float4*>(timr + 4 * jj);
-              v[4 * jj] += pr.x + tr.x; v[4 * jj + 1] += pr.y + tr.y; v[4 * jj + 2] += pr.z + tr.z; v[4 * jj + 3] += pr.w + tr.w;
-            }
-          }
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-            *reinterpret_cast<float4*>(o + 4 * jj) = make_float4(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
-        }
-      }
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
-    // a full tile issued exactly NSTORE stores after the (up to) two stages already in flight: for the
-    // next two waits those stores may stay outstanding; the third wait needs a stage issued after them.
-    grace = (full && !(p.ablate & 4)) ? 2 : 0;
-    if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (j + 1 < my_tiles) tile_coords(j + 1, m0, n0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (stamp) { const unsigned long long t = clock64(); tE += t - ts; ts = t; }
-    __builtin_amdgcn_s_barrier();               // closes the tile's last MFMA segment (+ epilogue)
-    __builtin_amdgcn_sched_barrier(0);
-    if (stamp) { const unsigned long long t = clock64(); tB2 += t - ts; ts = t; }
-  }
-  if (stamp && lane == 0) {
-    unsigned long long* d = p.dbg + (size_t)(blockIdx.x * 8 + wave) * 8;
-    d[0] = tL; d[1] = tB1; d[2] = tC; d[3] = tB2; d[4] = tE; d[5] = (unsigned long long)G;
-  }
-  if (wr == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra leading barrier
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy LDS-DMA before the LDS is released
-}
-
 template <class P, int KERN>
 int launch_256(GemmParams gp, int epi, hipStream_t s) {
   gp.tiles_m = (gp.M + 255) / 256;
@@ -1218,7 +926,6 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
   do {                                                                                             \
     if (KERN == 7) hipLaunchKernelGGL((gemm256r_kernel<P, EPI, RES, SPLIT, 2>), grid, block, 0, s, gp); \
     else if (KERN == 8) hipLaunchKernelGGL((gemm256r_kernel<P, EPI, RES, SPLIT, 4>), grid, block, 0, s, gp); \
-    else if (KERN == 5) hipLaunchKernelGGL((gemm256pp_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp); \
     else hipLaunchKernelGGL((gemm256_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp);         \
   } while (0)
   switch (epi) {
@@ -1255,7 +962,6 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   // fc1 0.55 vs 0.78 ms) and, since the static wave priority, for the deep-K N = 768 GEMM (fc2 0.59 vs
   // 0.62 ms); the shallow one (out, K = 768: 0.28 vs 0.26 ms) stays on the 128^2 kernel, whose many small
   // workgroups spread the fp32 residual traffic better over its short k-loop
-  if (gp.N % 256 == 0 && gp.K % 384 == 0 && variant == 5) return launch_256<P, 5>(gp, epi, s);
   const bool fits32r = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
   if (gp.N % 256 == 0 && gp.K >= 256 && fits32r && variant == 7) return launch_256<P, 7>(gp, epi, s);
   if (gp.N % 256 == 0 && gp.K >= 256 && fits32r && variant == 8) return launch_256<P, 8>(gp, epi, s);

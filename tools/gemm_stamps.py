@@ -1,9 +1,10 @@
 #!/usr/bin/env python
-"""Per-segment cycle shares of the ping-pong GEMM (v5) from in-kernel s_memtime stamps (diagnostic build path)."""
+"""Per-stage cycle shares of the persistent GEMM (v3) from in-kernel s_memtime stamps: vmcnt wait, barrier wait, stage
+body and epilogue, per wave group (gava_debug_set_buffer; no stamp executes in the product path)."""
 import ctypes as C, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-os.environ.setdefault("GAVA_GEMM_VARIANT", "5")   # 3: v3 (load = vmcnt wait, wait-b1 = barrier, mfma = stage body)
+os.environ.setdefault("GAVA_GEMM_VARIANT", "3")   # the persistent v3 kernel carries the stamps
 import torch
 from gava_clip_amd import hip
 lib = hip.load()
@@ -31,4 +32,4 @@ for grp, name in ((slice(0, 4), "group0 (waves 0-3)"), (slice(4, 8), "group1 (wa
     x = d[:, grp].reshape(-1, 8)
     G = x[:, 5].mean()
     tot = x[:, :5].sum(1).mean()
-    print(f"{which} {name}: stages/wave {G:.0f}; per stage cycles: load {x[:,0].mean()/G:.0f}  wait-b1 {x[:,1].mean()/G:.0f}  mfma {x[:,2].mean()/G:.0f}  wait-b2 {x[:,3].mean()/G:.0f}  epilogue {x[:,4].mean()/G:.0f}  total {tot/G:.0f}")
+    print(f"{which} {name}: stages/wave {G:.0f}; per stage cycles: vmcnt-wait {x[:,0].mean()/G:.0f}  barrier {x[:,1].mean()/G:.0f}  body {x[:,2].mean()/G:.0f}  epilogue {x[:,4].mean()/G:.0f}  total {tot/G:.0f}")
