@@ -12,11 +12,31 @@
 // q is expected pre-scaled by 1/sqrt(dh) (as the forward's QKV GEMM writes it); dq is multiplied by q_scale.
 #include "common.h"
 #include "internal.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int LDS_ROW = 160;  // bytes per row in LDS (64 x 2 B + 32 B pad): conflict-free for b128 and tr_b64 reads
 constexpr float LOG2E = 1.4426950408889634f;
+
+// Activations kept from the forward may be stored in another 16-bit type (PA, e.g. fp16) than the one the gradients
+// and the MFMAs use (P, bf16): convert 8 packed values on load.  PA == P compiles to nothing.
+template <class PA, class P>
+static __device__ __forceinline__ uint4 to_p(uint4 v) {
+  if constexpr (std::is_same<PA, P>::value) {
+    return v;
+  } else {
+    unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      w[e] = P::cvt2(PA::up((unsigned short)w[e]), PA::up((unsigned short)(w[e] >> 16)));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+template <class PA, class P>
+static __device__ __forceinline__ s16x8_t load_act8(const unsigned short* p) {
+  return __builtin_bit_cast(s16x8_t, to_p<PA, P>(*reinterpret_cast<const uint4*>(p)));
+}
 
 // key index -> row of the gathered prompt matrix (same as attention.hip)
 static __device__ __forceinline__ long side_row_of(const gava::AttnBwdMfmaParams& p, int frame, int sidx) {
@@ -25,7 +45,7 @@ static __device__ __forceinline__ long side_row_of(const gava::AttnBwdMfmaParams
                             : (long)p.n_g + p.batch + frame;
 }
 
-template <class P, int NKT>
+template <class P, class PA, int NKT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const gava::AttnBwdMfmaParams p) {
   constexpr int KP = NKT * 16;
   constexpr int NIT = (KP * 8 + 255) / 256;
@@ -58,8 +78,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const gava::AttnBwd
       const int row = id >> 3, chunk = id & 7;
       if (id < KP * 8) {
         const bool ok = row < p.n_keys;
-        *reinterpret_cast<uint4*>(Ks + row * LDS_ROW + chunk * 16) = ok ? kv[it] : make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(Vs + row * LDS_ROW + chunk * 16) = ok ? vv[it] : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(Ks + row * LDS_ROW + chunk * 16) = ok ? to_p<PA, P>(kv[it]) : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(Vs + row * LDS_ROW + chunk * 16) = ok ? to_p<PA, P>(vv[it]) : make_uint4(0, 0, 0, 0);
       }
     }
   }
@@ -71,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const gava::AttnBwd
     const int qrow = qi < p.n_q ? qi : p.n_q - 1;
     const unsigned short* qp = p.q + (row0 + qrow) * p.ld_qkv + h * 64 + 8 * fg;
     const unsigned short* op = p.dout + (row0 + qrow) * p.ld_dout + h * 64 + 8 * fg;
-    const s16x8_t q0 = *reinterpret_cast<const s16x8_t*>(qp), q1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
+    const s16x8_t q0 = load_act8<PA, P>(qp), q1 = load_act8<PA, P>(qp + 32);
     const s16x8_t g0 = *reinterpret_cast<const s16x8_t*>(op), g1 = *reinterpret_cast<const s16x8_t*>(op + 32);
 
     // S^T = K Q^T and dP^T = V dO^T: lane holds, for its query fr, keys kt*16 + 4*fg + r
@@ -201,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const gava::AttnBwd
   }
 }
 
-template <class P, int NQT>
+template <class P, class PA, int NQT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const gava::AttnBwdMfmaParams p) {
   static_assert(NQT % 2 == 0, "query tiles are consumed in pairs (32-deep MFMA contraction)");
   constexpr int QP = NQT * 16;
@@ -236,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const gava::AttnBw
       const int row = id >> 3, chunk = id & 7;
       if (id < QP * 8) {
         const bool ok = row < p.n_q;
-        *reinterpret_cast<uint4*>(Qs + row * LDS_ROW + chunk * 16) = ok ? qv[it] : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(Qs + row * LDS_ROW + chunk * 16) = ok ? to_p<PA, P>(qv[it]) : make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(Os + row * LDS_ROW + chunk * 16) = ok ? ov[it] : make_uint4(0, 0, 0, 0);
       }
     }
@@ -259,8 +279,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const gava::AttnBw
     const unsigned short* kp = (is_main ? p.k : p.sk) + koff;
     const unsigned short* vp = (is_main ? p.v : p.sv) + koff;
     // B operands: this lane's key, head dims 8*fg.. and 32 + 8*fg..
-    const s16x8_t kb0 = *reinterpret_cast<const s16x8_t*>(kp), kb1 = *reinterpret_cast<const s16x8_t*>(kp + 32);
-    const s16x8_t vb0 = *reinterpret_cast<const s16x8_t*>(vp), vb1 = *reinterpret_cast<const s16x8_t*>(vp + 32);
+    const s16x8_t kb0 = load_act8<PA, P>(kp), kb1 = load_act8<PA, P>(kp + 32);
+    const s16x8_t vb0 = load_act8<PA, P>(vp), vb1 = load_act8<PA, P>(vp + 32);
     f32x4_t dv[4], dk[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dk[dt] = dv[dt]; }
@@ -342,19 +362,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const gava::AttnBw
   }
 }
 
-template <class P>
+template <class P, class PA>
 int launch(const gava::AttnBwdMfmaParams& p, hipStream_t s) {
   dim3 grid(p.batch * p.heads), block(256);
   const int kt = (p.n_keys + 15) / 16, qt2 = ((p.n_q + 15) / 16 + 1) / 2 * 2;
-  if (kt <= 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, 2>), grid, block, 0, s, p);
-  else if (kt <= 6) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, 6>), grid, block, 0, s, p);
-  else if (kt <= 14) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, 14>), grid, block, 0, s, p);
-  else if (kt <= 20) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, 20>), grid, block, 0, s, p);
+  if (kt <= 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, PA, 2>), grid, block, 0, s, p);
+  else if (kt <= 6) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, PA, 6>), grid, block, 0, s, p);
+  else if (kt <= 14) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, PA, 14>), grid, block, 0, s, p);
+  else if (kt <= 20) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, PA, 20>), grid, block, 0, s, p);
   else return GAVA_EINVAL;
-  if (qt2 <= 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, 2>), grid, block, 0, s, p);
-  else if (qt2 <= 6) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, 6>), grid, block, 0, s, p);
-  else if (qt2 <= 14) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, 14>), grid, block, 0, s, p);
-  else if (qt2 <= 18) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, 18>), grid, block, 0, s, p);
+  if (qt2 <= 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, PA, 2>), grid, block, 0, s, p);
+  else if (qt2 <= 6) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, PA, 6>), grid, block, 0, s, p);
+  else if (qt2 <= 14) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, PA, 14>), grid, block, 0, s, p);
+  else if (qt2 <= 18) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, PA, 18>), grid, block, 0, s, p);
   else return GAVA_EINVAL;
   GAVA_CHECK_LAUNCH();
   return GAVA_OK;
@@ -363,9 +383,10 @@ int launch(const gava::AttnBwdMfmaParams& p, hipStream_t s) {
 }  // namespace
 
 namespace gava {
-int attention_bwd_mfma(const AttnBwdMfmaParams& p, int prec, hipStream_t s) {
-  if (prec == GAVA_PREC_F16) return launch<PrecF16>(p, s);
-  if (prec == GAVA_PREC_BF16) return launch<PrecBF16>(p, s);
+int attention_bwd_mfma(const AttnBwdMfmaParams& p, int prec, int act_prec, hipStream_t s) {
+  if (prec == GAVA_PREC_F16 && act_prec == GAVA_PREC_F16) return launch<PrecF16, PrecF16>(p, s);
+  if (prec == GAVA_PREC_BF16 && act_prec == GAVA_PREC_BF16) return launch<PrecBF16, PrecBF16>(p, s);
+  if (prec == GAVA_PREC_BF16 && act_prec == GAVA_PREC_F16) return launch<PrecBF16, PrecF16>(p, s);   // fp16 forward, bf16 gradients
   return GAVA_EINVAL;
 }
 }  // namespace gava

@@ -269,7 +269,7 @@ extern "C" int gava_attention_backward(const gava_attention_bwd_args* a, gava_st
   p.q_pad = ((p.n_q + 15) / 16 + 1) / 2 * 32;
   p.q_scale = a->q_scale;
   if (p.n_keys > 320 || p.n_q > a->n || p.n_q > 288) return GAVA_EINVAL;
-  return gava::attention_bwd_mfma(p, a->prec, s);
+  return gava::attention_bwd_mfma(p, a->prec, a->act_prec_set ? a->act_prec : a->prec, s);
 }
 
 extern "C" size_t gava_attention_backward_workspace_bytes(int batch, int heads, int n_q) {

@@ -57,11 +57,11 @@ int ln(const float* in, long in_stride, const int32_t* idx, const float* g, cons
 
 int gemm(const void* A, long lda, const void* W, long ldw, const float* bias, void* out, long ldo, int M, int N, int K,
          int epi, int prec, gava_stream_t s, const float* resid = nullptr, long ldr = 0, int scale_cols = 0,
-         float scale = 1.f, int split_out = 0) {
+         float scale = 1.f, int split_out = 0, void* aux_out = nullptr) {
   gava_gemm_args a{};
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo;
   a.resid = resid; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.prec = prec;
-  a.scale_cols = scale_cols; a.scale = scale; a.split_out = split_out;
+  a.scale_cols = scale_cols; a.scale = scale; a.split_out = split_out; a.aux_out = aux_out;
   return gava_gemm(&a, s);
 }
 
@@ -247,6 +247,93 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
   // ---- head (VitaCLIP_vision_encoder.py:126-130)
   // split precision (3 MFMA passes): M = BT rows only, and its rounding lands directly on the output
   TRY(ln(w.X, fs, nullptr, m->lnpost_g, m->lnpost_b, w.CLSPOST, 3 * D, nullptr, 0, BT, D, pr, stream, 1));
+  TRY(gemm(w.CLSPOST, 3 * D, m->w_proj, 3 * D, nullptr, w.PROJ, E, BT, E, 3 * D, GAVA_EPI_F32, pr, stream));
+  TRY(gava::mean_rows(w.PROJ, cls_x, m->B, m->T_in, E, s));
+  TRY(gava::mean_rows(w.SUMM, summary, BT / Tm, Tm, D, s));
+  return GAVA_OK;
+}
+
+// Training forward that KEEPS the activations the backward needs instead of leaving them to be recomputed
+// (288 GB of HBM: ~21 GB at c2).  Nothing is copied: the residual stream hops from buffer to buffer
+// (x[i] -> x1[i] -> x[i+1], the GEMMs' residual input and output being different pointers), the QKV GEMM and the prompt
+// path write straight into the per-block slots, and fc1 stores its pre-activation beside the QuickGELU output.
+// Every block runs in full (no CLS-only shortcut in the last one: its keys/values need gradients anyway).
+extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float* x, float* cls_x, float* summary,
+                                        const gava_vision_saved* sv, void* workspace, size_t workspace_bytes,
+                                        gava_stream_t stream) {
+  TRY(check_vision(m));
+  if (!x || !cls_x || !summary || !workspace || !sv || !sv->e0 || !sv->x || !sv->x1 || !sv->qkv || !sv->pre || !sv->sidekv)
+    return GAVA_EINVAL;
+  const VisionWs w = carve_vision(m, workspace, workspace_bytes);
+  if (w.total > workspace_bytes) return GAVA_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  gava::set_gemm_cu_reserve(0);
+  const int g = m->size / m->P, n = g * g, BT = m->B * m->T_in, R = BT * (n + 1);
+  const int D = m->D, F = m->F, E = m->E, G = m->G, Tm = m->T_model, pr = m->prec;
+  const int Kp = patch_k(m), SR = G + 2 * BT;
+  const long fs = (long)(n + 1) * D;
+  const size_t RD = (size_t)R * D;
+  {
+    gava_gemm_args a{};
+    a.A = nullptr; a.lda = Kp; a.frames = x; a.frame_size = m->size; a.patch = m->P;
+    a.W = m->w_patch; a.ldw = Kp; a.bias = m->b_patch;
+    a.out = sv->e0; a.ldo = D; a.M = BT * n; a.N = D; a.K = Kp; a.epilogue = GAVA_EPI_F32_PATCH; a.prec = pr;
+    a.pos = m->pos_embed; a.time = m->time_embed; a.n_patches = n; a.T = m->T_in;
+    TRY(gava_gemm(&a, stream));
+  }
+  TRY(gava::cls_embed(sv->e0, m->cls_token, m->pos_embed, m->time_embed, BT, m->T_in, D, fs, s));
+  TRY(ln(sv->e0, D, nullptr, m->lnpre_g, m->lnpre_b, nullptr, 0, sv->x, D, R, D, pr, stream));
+  for (int i = 0; i < m->layers; ++i) {
+    const gava_vision_layer& L = m->layer[i];
+    const unsigned short* wqkv = (const unsigned short*)L.w_qkv;
+    float* Xin = sv->x + (size_t)i * RD;
+    float* X1 = sv->x1 + (size_t)i * RD;
+    float* Xout = sv->x + (size_t)(i + 1) * RD;
+    unsigned short* QKV = (unsigned short*)sv->qkv + (size_t)i * R * 3 * D;
+    unsigned short* PRE = (unsigned short*)sv->pre + (size_t)i * R * F;
+    unsigned short* SKV = (unsigned short*)sv->sidekv + (size_t)i * SR * 2 * D;
+    const bool two = g_side.get() && m->layers <= 64;
+    gava_stream_t ss = two ? (gava_stream_t)g_side.s : stream;
+    if (two) {
+      if (hipEventRecord(g_side.fork[i], s) != hipSuccess || hipStreamWaitEvent(g_side.s, g_side.fork[i], 0) != hipSuccess)
+        return GAVA_ELAUNCH;
+    }
+    TRY(ln(Xin, fs, nullptr, nullptr, nullptr, w.CLS16, D, nullptr, 0, BT, D, pr, ss));
+    TRY(gemm(w.CLS16, D, L.w_cls, D, L.b_cls, w.CP, D, BT, D, D, GAVA_EPI_F32, pr, ss));
+    TRY(ln(w.CP, D, nullptr, L.sln_g, L.sln_b, w.CPn, D, nullptr, 0, BT, D, pr, ss));
+    TRY(gemm(w.CPn, D, L.w_sqkv, D, L.b_sqkv, w.SQKV, 3 * D, BT, 3 * D, D, GAVA_EPI_H16, pr, ss, nullptr, 0, D, 0.125f));
+    {
+      gava_attention_args a{};
+      const unsigned short* q = (const unsigned short*)w.SQKV;
+      a.q = q; a.k = q + D; a.v = q + 2 * D; a.ld_qkv = 3 * D; a.out = w.SMIX; a.ld_out = D;
+      a.batch = BT / Tm; a.heads = m->H; a.n_q = Tm; a.n_kmain = Tm; a.prec = pr;
+      TRY(gava_attention(&a, ss));
+    }
+    TRY(gemm(w.SMIX, D, L.w_sout, D, L.b_sout, w.SUMM, D, BT, D, D, GAVA_EPI_F32, pr, ss, w.CP, D));
+    TRY(gava::side_ln(L.global_prompts, L.local_prompts, w.CP, w.SUMM, L.ln1_g, L.ln1_b, w.SIDEn, G, Tm, BT, D, pr, (hipStream_t)ss));
+    TRY(gemm(w.SIDEn, D, wqkv + (long)D * D, D, L.b_qkv + D, SKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, ss));
+    if (two && hipEventRecord(g_side.join[i], g_side.s) != hipSuccess) return GAVA_ELAUNCH;
+    gava::set_gemm_cu_reserve(two ? 8 : 0);
+    TRY(ln(Xin, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
+    TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+    gava::set_gemm_cu_reserve(0);
+    if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
+    {
+      gava_attention_args a{};
+      a.q = QKV; a.k = QKV + D; a.v = QKV + 2 * D; a.ld_qkv = 3 * D;
+      a.side_k = SKV; a.side_v = SKV + D; a.ld_side = 2 * D;
+      a.out = w.MIX; a.ld_out = D;
+      a.batch = BT; a.heads = m->H; a.n_q = n + 1; a.n_kmain = n + 1;
+      a.n_g = G; a.T = Tm; a.has_summary = 1; a.prec = pr;
+      TRY(gava_attention(&a, stream));
+    }
+    TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, X1, D, R, D, D, GAVA_EPI_F32, pr, stream, Xin, D));
+    TRY(ln(X1, D, nullptr, L.ln2_g, L.ln2_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
+    TRY(gemm(w.Xn, D, L.w_fc1, D, L.b_fc1, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, 0, PRE));
+    TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, Xout, D, R, D, F, GAVA_EPI_F32, pr, stream, X1, D));
+  }
+  const float* Xf = sv->x + (size_t)m->layers * RD;
+  TRY(ln(Xf, fs, nullptr, m->lnpost_g, m->lnpost_b, w.CLSPOST, 3 * D, nullptr, 0, BT, D, pr, stream, 1));
   TRY(gemm(w.CLSPOST, 3 * D, m->w_proj, 3 * D, nullptr, w.PROJ, E, BT, E, 3 * D, GAVA_EPI_F32, pr, stream));
   TRY(gava::mean_rows(w.PROJ, cls_x, m->B, m->T_in, E, s));
   TRY(gava::mean_rows(w.SUMM, summary, BT / Tm, Tm, D, s));

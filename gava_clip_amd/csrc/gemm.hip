@@ -36,6 +36,8 @@ struct GemmParams {
   void* out; long ldo;
   const float* resid; long ldr;
   const unsigned short* aux;   // EPI_H16_QGELU_BWD: pre-activations, laid out as out
+  int aux_f16;                 // ... stored as fp16 (else bf16), independent of the operand precision
+  unsigned short* aux_out;     // EPI_H16_QGELU: optional copy of the pre-activation (training forward)
   int M, N, K;
   int scale_cols; float scale;
   const float* pos; const float* time; int n_patches; int T;
@@ -46,6 +48,10 @@ struct GemmParams {
   unsigned long long* dbg;  // debug only: per-wave segment cycle sums (gava_debug_set_buffer)
   int ablate;   // debug only (GAVA_GEMM_ABLATE): 1 = no staging loads after the prologue, 2 = no LDS reads/MFMA
 };
+
+static __device__ __forceinline__ float aux_up(unsigned short u, int f16) {
+  return f16 ? PrecF16::up(u) : PrecBF16::up(u);
+}
 
 template <class P, int EPI, bool RES, bool SPLIT, int BM, int BN, int NST>
 __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2)
@@ -259,11 +265,12 @@ void gemm_kernel(const GemmParams p) {
         if (EPI == GAVA_EPI_H16) {
           if (n < p.scale_cols) { v0 *= p.scale; v1 *= p.scale; v2 *= p.scale; v3 *= p.scale; }
         } else if (EPI == GAVA_EPI_H16_QGELU) {
+          if (p.aux_out) *reinterpret_cast<uint2*>(p.aux_out + orow * p.ldo + n) = pack4<P>(v0, v1, v2, v3);
           v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3);
         } else {
           const uint2 ax = *reinterpret_cast<const uint2*>(p.aux + orow * p.ldo + n);
-          v0 *= quick_gelu_grad(P::up((unsigned short)ax.x)); v1 *= quick_gelu_grad(P::up((unsigned short)(ax.x >> 16)));
-          v2 *= quick_gelu_grad(P::up((unsigned short)ax.y)); v3 *= quick_gelu_grad(P::up((unsigned short)(ax.y >> 16)));
+          v0 *= quick_gelu_grad(aux_up((unsigned short)ax.x, p.aux_f16)); v1 *= quick_gelu_grad(aux_up((unsigned short)(ax.x >> 16), p.aux_f16));
+          v2 *= quick_gelu_grad(aux_up((unsigned short)ax.y, p.aux_f16)); v3 *= quick_gelu_grad(aux_up((unsigned short)(ax.y >> 16), p.aux_f16));
         }
         unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + n;
         if (SPLIT) {
@@ -542,6 +549,15 @@ void gemm256_kernel(const GemmParams p) {
               for (int e = 0; e < 16; ++e) v[e] *= p.scale;
             }
           } else if (EPI == GAVA_EPI_H16_QGELU) {
+            if (p.aux_out) {
+              unsigned short* ao = p.aux_out + orow * p.ldo + nb0;
+#pragma unroll
+              for (int hh = 0; hh < 2; ++hh) {
+                const uint2 x = pack4<P>(v[8 * hh], v[8 * hh + 1], v[8 * hh + 2], v[8 * hh + 3]);
+                const uint2 y = pack4<P>(v[8 * hh + 4], v[8 * hh + 5], v[8 * hh + 6], v[8 * hh + 7]);
+                *reinterpret_cast<uint4*>(ao + 8 * hh) = make_uint4(x.x, x.y, y.x, y.y);
+              }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = quick_gelu(v[e]);
           } else {
@@ -550,8 +566,8 @@ void gemm256_kernel(const GemmParams p) {
             const unsigned aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              v[2 * e] *= quick_gelu_grad(P::up((unsigned short)aw[e]));
-              v[2 * e + 1] *= quick_gelu_grad(P::up((unsigned short)(aw[e] >> 16)));
+              v[2 * e] *= quick_gelu_grad(aux_up((unsigned short)aw[e], p.aux_f16));
+              v[2 * e + 1] *= quick_gelu_grad(aux_up((unsigned short)(aw[e] >> 16), p.aux_f16));
             }
           }
           unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + nb0;
@@ -602,7 +618,7 @@ void gemm256_kernel(const GemmParams p) {
     // a full tile issued exactly NSTORE stores per wave after the in-flight stage: they may stay in flight
     // over the next wait (ragged tiles store fewer, and the accumulator-residual loads add to the count:
     // those cases fall back to vmcnt(0)).
-    counted = full && !ACC_RES && !(p.ablate & 4);
+    counted = full && !ACC_RES && !(p.ablate & 4) && !(EPI == GAVA_EPI_H16_QGELU && p.aux_out);
     m0 = m0n; n0 = n0n;
   }
   if (stamp && lane == 0) {
@@ -990,7 +1006,9 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   if (a->bias && ((uintptr_t)a->bias & 15)) return GAVA_EINVAL;
   if (a->ldo % 4 || a->ldo < (a->split_out ? 3 : 1) * (int64_t)a->N) return GAVA_EINVAL;
   if (a->split_out && a->epilogue != GAVA_EPI_H16 && a->epilogue != GAVA_EPI_H16_QGELU) return GAVA_EINVAL;
-  if (a->epilogue == GAVA_EPI_H16_QGELU_BWD && (!a->aux || ((uintptr_t)a->aux & 15) || a->ldo % 8)) return GAVA_EINVAL;
+  if (a->epilogue == GAVA_EPI_H16_QGELU_BWD && (!a->aux || ((uintptr_t)a->aux & 15) || a->ldo % 8 ||
+                                               (a->aux_prec != GAVA_PREC_F16 && a->aux_prec != GAVA_PREC_BF16))) return GAVA_EINVAL;
+  if (a->aux_out && (a->epilogue != GAVA_EPI_H16_QGELU || a->split_out || ((uintptr_t)a->aux_out & 15) || a->ldo % 8)) return GAVA_EINVAL;
   if (a->epilogue == GAVA_EPI_F32 && a->resid && (a->ldr % 4 || ((uintptr_t)a->resid & 15))) return GAVA_EINVAL;
   if (a->epilogue == GAVA_EPI_F32_PATCH &&
       (!a->pos || !a->time || a->n_patches <= 0 || a->T <= 0 || a->M % a->n_patches)) return GAVA_EINVAL;
@@ -999,7 +1017,7 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.W = (const unsigned short*)a->W; gp.ldw = a->ldw;
   gp.bias = a->bias; gp.out = a->out; gp.ldo = a->ldo;
   gp.resid = a->resid; gp.ldr = a->ldr;
-  gp.aux = (const unsigned short*)a->aux;
+  gp.aux = (const unsigned short*)a->aux; gp.aux_f16 = a->aux_prec == GAVA_PREC_F16; gp.aux_out = (unsigned short*)a->aux_out;
   gp.M = a->M; gp.N = a->N; gp.K = a->K;
   gp.scale_cols = a->scale_cols; gp.scale = a->scale;
   gp.pos = a->pos; gp.time = a->time; gp.n_patches = a->n_patches; gp.T = a->T;

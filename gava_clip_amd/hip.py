@@ -20,7 +20,7 @@ EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_vision_workspace_bytes", "gava_vision_forward", "gava_text_workspace_bytes",
            "gava_text_forward", "gava_similarity_head", "gava_convert_h16", "gava_debug_set_buffer",
            "gava_preprocess_clip", "gava_layernorm_backward", "gava_qgelu_backward", "gava_attention_backward",
-           "gava_text_forward_train", "gava_vision_forward_train", "gava_attention_backward_workspace_bytes"]
+           "gava_text_forward_train", "gava_vision_forward_train", "gava_attention_backward_workspace_bytes", "gava_vision_forward_keep"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 
@@ -32,7 +32,7 @@ class GemmArgs(C.Structure):
                 ("scale_cols", C.c_int), ("scale", C.c_float),
                 ("pos", _fp), ("time", _fp), ("n_patches", C.c_int), ("T", C.c_int),
                 ("frames", _fp), ("frame_size", C.c_int), ("patch", C.c_int), ("split_out", C.c_int),
-                ("aux", _vp)]
+                ("aux", _vp), ("aux_prec", C.c_int), ("aux_out", _vp)]
 
 
 class LayerNormArgs(C.Structure):
@@ -87,6 +87,10 @@ class PreprocessArgs(C.Structure):
                 ("out", _fp), ("out_stride_c", C.c_int64), ("out_stride_t", C.c_int64)]
 
 
+class VisionSaved(C.Structure):
+    _fields_ = [("e0", _fp), ("x", _fp), ("x1", _fp), ("qkv", _vp), ("pre", _vp), ("sidekv", _vp)]
+
+
 class LayerNormBwdArgs(C.Structure):
     _fields_ = [("x", _fp), ("x_stride", C.c_int64), ("x_row_index", _ip), ("gamma", _fp),
                 ("dy", _fp), ("dy_stride", C.c_int64),
@@ -102,7 +106,8 @@ class AttentionBwdArgs(C.Structure):
                 ("q_scale", C.c_float),
                 ("side_k", _vp), ("side_v", _vp), ("ld_side", C.c_int64),
                 ("dside_k", _fp), ("dside_v", _fp), ("ld_dside", C.c_int64),
-                ("n_g", C.c_int), ("T", C.c_int), ("has_summary", C.c_int), ("n_q", C.c_int), ("workspace", _vp)]
+                ("n_g", C.c_int), ("T", C.c_int), ("has_summary", C.c_int), ("n_q", C.c_int), ("workspace", _vp),
+                ("act_prec_set", C.c_int), ("act_prec", C.c_int)]
 
 
 _lib = None
@@ -153,6 +158,8 @@ def load():
     lib.gava_attention_backward.restype = C.c_int
     lib.gava_attention_backward_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.gava_attention_backward_workspace_bytes.restype = C.c_size_t
+    lib.gava_vision_forward_keep.argtypes = [C.POINTER(VisionModel), _fp, _fp, _fp, C.POINTER(VisionSaved), _vp, C.c_size_t, _vp]
+    lib.gava_vision_forward_keep.restype = C.c_int
     lib.gava_vision_forward_train.argtypes = [C.POINTER(VisionModel), _fp, _fp, _fp, _fp, _fp, _vp, C.c_size_t, _vp]
     lib.gava_vision_forward_train.restype = C.c_int
     lib.gava_text_forward_train.argtypes = [C.POINTER(TextModel), _ip, _fp, _ip, _fp, _fp, _vp, C.c_size_t, _vp]
@@ -185,9 +192,11 @@ def h16_dtype(prec):
 # ---- thin per-op wrappers (used by the unit tests; the model uses the fused drivers) ----------
 
 def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0,
-         pos=None, time=None, n_patches=0, T=0, M=None, split_out=False, frames=None, frame_size=0, patch=0, aux=None):
+         pos=None, time=None, n_patches=0, T=0, M=None, split_out=False, frames=None, frame_size=0, patch=0, aux=None,
+         aux_prec=None, aux_out=None):
     a = GemmArgs()
-    a.aux = ptr(aux)
+    a.aux, a.aux_out = ptr(aux), ptr(aux_out)
+    a.aux_prec = prec if aux_prec is None else aux_prec
     a.A, a.lda, a.W, a.ldw = ptr(A), (A.stride(0) if A is not None else W.stride(0)), ptr(W), W.stride(0)
     a.frames, a.frame_size, a.patch = ptr(frames), frame_size, patch
     a.bias, a.out, a.ldo = ptr(bias), ptr(out), out.stride(0)
@@ -273,8 +282,10 @@ def qgelu_backward(pre, dh, dpre, prec):
 
 
 def attention_backward(q, k, v, dout, dq, dk, dv, *, batch, heads, n, prec, causal=False, q_scale=1.0,
-                       side_k=None, side_v=None, dside_k=None, dside_v=None, n_g=0, T=0, has_summary=False, n_q=0):
+                       side_k=None, side_v=None, dside_k=None, dside_v=None, n_g=0, T=0, has_summary=False, n_q=0,
+                       act_prec=None):
     a = AttentionBwdArgs()
+    a.act_prec_set, a.act_prec = int(act_prec is not None), (act_prec if act_prec is not None else prec)
     a.side_k, a.side_v = ptr(side_k), ptr(side_v)
     a.ld_side = side_k.stride(0) if side_k is not None else 0
     a.dside_k, a.dside_v = ptr(dside_k), ptr(dside_v)

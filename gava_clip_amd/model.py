@@ -401,6 +401,9 @@ class VitaCLIP(nn.Module):
         # independent; opt-in because a benchmark must not skip work.  Invalidated by any parameter update.
         self.cache_text_features = False
         self.text_on_side_stream = os.environ.get("GAVA_TEXT_STREAM", "1") != "0"
+        # training: keep the backward's activations (~21 GB at B = 64, T = 8) instead of recomputing them per block, as
+        # long as they fit this budget; beyond it the backward recomputes from the block inputs only
+        self.keep_activation_bytes = int(float(os.environ.get("GAVA_KEEP_ACT_GB", "96")) * 2 ** 30)
         self._text_stream = None
         self._text_cache = None
         self.gather_across_ranks = True     # RCCL all-gather of clip embeddings when world_size > 1
@@ -556,9 +559,10 @@ class VitaCLIP(nn.Module):
         return ws
 
     # ---- encoders -----------------------------------------------------------------------------
-    def encode_video(self, x, saved=None):
+    def encode_video(self, x, saved=None, kept=None):
         """CLIPVisionEncoder.forward on the HIP path -> (cls_x (B,E), summary (B,D)), fp32.
-        saved: optional fp32 [layers+2, B*T*(n+1), D] that receives what the backward recomputes from."""
+        saved: optional fp32 [layers+2, B*T*(n+1), D] that receives what the backward recomputes from;
+        kept: optional dict of per-block activation buffers (training.alloc_kept) filled by gava_vision_forward_keep."""
         if not x.is_cuda:
             raise hip.GavaError("VitaCLIP (gava_clip_amd) runs on the HIP device only: move the model and the "
                                 "input with .cuda(); there is no CPU fallback")
@@ -587,9 +591,15 @@ class VitaCLIP(nn.Module):
         cls_x = torch.empty(B, sh["E"], dtype=torch.float32, device=x.device)
         summary = torch.empty(B * T // self.num_frames, sh["D"], dtype=torch.float32, device=x.device)
         dbg = torch.empty(sh["layers"], B * T, sh["D"], dtype=torch.float32, device=x.device) if self.debug_taps else None
-        hip.check(lib.gava_vision_forward_train(C.byref(m), hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), hip.ptr(dbg),
-                                                hip.ptr(saved), hip.ptr(ws), ws.numel(), hip.stream_ptr()),
-                  "gava_vision_forward")
+        if kept is not None:
+            sv = hip.VisionSaved(hip.ptr(kept["e0"]), hip.ptr(kept["x"]), hip.ptr(kept["x1"]), hip.ptr(kept["qkv"]),
+                                 hip.ptr(kept["pre"]), hip.ptr(kept["sidekv"]))
+            hip.check(lib.gava_vision_forward_keep(C.byref(m), hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), C.byref(sv),
+                                                   hip.ptr(ws), ws.numel(), hip.stream_ptr()), "gava_vision_forward_keep")
+        else:
+            hip.check(lib.gava_vision_forward_train(C.byref(m), hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), hip.ptr(dbg),
+                                                    hip.ptr(saved), hip.ptr(ws), ws.numel(), hip.stream_ptr()),
+                      "gava_vision_forward")
         self.last["cls_rows"] = dbg
         return cls_x, summary
 

@@ -209,9 +209,29 @@ def _wgrad(dy16, x16):
     return out
 
 
-def vision_backward(model, saved, dcls_x, B, T, dsummary=None):
+def kept_bytes(model, B, T):
+    sh = model._shape
+    n1 = (sh["size"] // sh["P"]) ** 2 + 1
+    R, D, F, NL = B * T * n1, sh["D"], sh["F"], sh["layers"]
+    return R * D * 4 * (2 * NL + 2) + NL * (R * 3 * D * 2 + R * F * 2 + (sh["G"] + 2 * B * T) * 2 * D * 2)
+
+
+def alloc_kept(model, B, T, device):
+    """Per-block activation buffers for gava_vision_forward_keep (include/gava_hip.h, gava_vision_saved)."""
+    sh = model._shape
+    n1 = (sh["size"] // sh["P"]) ** 2 + 1
+    R, D, F, NL, SR = B * T * n1, sh["D"], sh["F"], sh["layers"], sh["G"] + 2 * B * T
+    h16 = hip.h16_dtype(model.prec)
+    e = lambda *s, dtype=torch.float32: torch.empty(*s, dtype=dtype, device=device)
+    return dict(e0=e(R, D), x=e(NL + 1, R, D), x1=e(NL, R, D), qkv=e(NL, R, 3 * D, dtype=h16), pre=e(NL, R, F, dtype=h16),
+                sidekv=e(NL, SR, 2 * D, dtype=h16))
+
+
+def vision_backward(model, saved, dcls_x, B, T, dsummary=None, kept=None):
     """d cls_x (B,E) [+ d summary (B,D), the auxiliary NTE head's input] -> {parameter name: gradient} for the trainable
-    vision parameters."""
+    vision parameters.  `kept` (alloc_kept, filled by the forward) replaces the per-block recomputation of the main rows:
+    activations are then in the forward's operand type (fp16 by default) while gradients stay bf16 - the attention
+    backward converts K/V/Q as it stages them, the QuickGELU' epilogue decodes the pre-activation by its own flag."""
     sh = model._shape
     bw = model._pack_vision_backward()
     D, H, F, E, G, NL = sh["D"], sh["H"], sh["F"], sh["E"], sh["G"], sh["layers"]
@@ -230,16 +250,20 @@ def vision_backward(model, saved, dcls_x, B, T, dsummary=None):
     dclspost = new(BT, D, dtype=torch.float32)
     hip.gemm(hip.convert_h16(dproj, BWD), bw["proj"], None, dclspost, epilogue=hip.EPI_F32, prec=BWD)
     dX = torch.zeros(R, D, dtype=torch.float32, device=dev)
-    hip.layernorm_backward(saved[NL + 1], v.ln_post.weight.detach().float().contiguous(), dclspost, dX,
+    x_final = kept["x"][NL] if kept is not None else saved[NL + 1]
+    hip.layernorm_backward(x_final, v.ln_post.weight.detach().float().contiguous(), dclspost, dX,
                            x_row_index=cls_idx, dx_row_index=cls_idx, rows=BT)
 
-    xn, qkv, mix, pre = new(R, D), new(R, 3 * D), new(R, D), new(R, F)
-    X1, dx16, dhid, dmix, dqkv = new(R, D, dtype=torch.float32), new(R, D), new(R, F), new(R, D), new(R, 3 * D)
+    if kept is None:
+        xn, qkv_buf, mix, pre_buf, X1_buf = new(R, D), new(R, 3 * D), new(R, D), new(R, F), new(R, D, dtype=torch.float32)
+    dx16, dhid, dmix, dqkv = new(R, D), new(R, F), new(R, D), new(R, 3 * D)
     dxn = new(R, D, dtype=torch.float32)
     conv(dX, dx16)
     dgp = torch.zeros_like(v.global_prompts, dtype=torch.float32)
     for i in reversed(range(NL)):
-        P, blk, X0 = bw["layers"][i], v.blocks[i], saved[1 + i]
+        P, blk = bw["layers"][i], v.blocks[i]
+        X0 = kept["x"][i] if kept is not None else saved[1 + i]
+        ACT = model.prec if kept is not None else BWD          # storage type of the activations used below
         f32 = lambda p: p.detach().float().contiguous()
         ln1_g, ln1_b, ln2_g, ln2_b = f32(blk.norm1.weight), f32(blk.norm1.bias), f32(blk.norm2.weight), f32(blk.norm2.bias)
         sln_g, sln_b = f32(blk.summary_ln.weight), f32(blk.summary_ln.bias)
@@ -259,21 +283,25 @@ def vision_backward(model, saved, dcls_x, B, T, dsummary=None):
         hip.gemm(SMIX, P["w_sout"], f32(s.out_proj.bias), SUMM, epilogue=hip.EPI_F32, prec=BWD, resid=CP)
         lp = blk.local_prompts.detach().float()[0]                                     # (T, D)
         SIDE = torch.cat([v.global_prompts.detach().float()[i], (CP.view(B, T, D) + lp).view(BT, D), SUMM], 0).contiguous()
-        SIDEn = new(SR, D)
-        hip.layernorm(SIDE, ln1_g, ln1_b, out16=SIDEn, prec=BWD)
-        SIDEKV = new(SR, 2 * D)
-        hip.gemm(SIDEn, P["w_kv"], P["b_qkv"][D:], SIDEKV, epilogue=hip.EPI_H16, prec=BWD)
-        # ---- recompute: main rows
-        hip.layernorm(X0, ln1_g, ln1_b, out16=xn, prec=BWD)
-        hip.gemm(xn, P["w_qkv"], P["b_qkv"], qkv, epilogue=hip.EPI_H16, prec=BWD, scale_cols=D, scale=0.125)
-        hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], mix, batch=BT, heads=H, n_q=n1, n_kmain=n1, prec=BWD,
-                      side_k=SIDEKV[:, :D], side_v=SIDEKV[:, D:], n_g=G, T=T, has_summary=True)
-        hip.gemm(mix, P["w_out"], P["b_out"], X1, epilogue=hip.EPI_F32, prec=BWD, resid=X0)
-        hip.layernorm(X1, ln2_g, ln2_b, out16=xn, prec=BWD)
-        hip.gemm(xn, P["w_fc1"], P["b_fc1"], pre, epilogue=hip.EPI_H16, prec=BWD)
+        if kept is not None:
+            SIDEKV, qkv, X1, pre = kept["sidekv"][i], kept["qkv"][i], kept["x1"][i], kept["pre"][i]
+        else:
+            SIDEn = new(SR, D)
+            hip.layernorm(SIDE, ln1_g, ln1_b, out16=SIDEn, prec=BWD)
+            SIDEKV = new(SR, 2 * D)
+            hip.gemm(SIDEn, P["w_kv"], P["b_qkv"][D:], SIDEKV, epilogue=hip.EPI_H16, prec=BWD)
+            # ---- recompute: main rows
+            qkv, X1, pre = qkv_buf, X1_buf, pre_buf
+            hip.layernorm(X0, ln1_g, ln1_b, out16=xn, prec=BWD)
+            hip.gemm(xn, P["w_qkv"], P["b_qkv"], qkv, epilogue=hip.EPI_H16, prec=BWD, scale_cols=D, scale=0.125)
+            hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], mix, batch=BT, heads=H, n_q=n1, n_kmain=n1, prec=BWD,
+                          side_k=SIDEKV[:, :D], side_v=SIDEKV[:, D:], n_g=G, T=T, has_summary=True)
+            hip.gemm(mix, P["w_out"], P["b_out"], X1, epilogue=hip.EPI_F32, prec=BWD, resid=X0)
+            hip.layernorm(X1, ln2_g, ln2_b, out16=xn, prec=BWD)
+            hip.gemm(xn, P["w_fc1"], P["b_fc1"], pre, epilogue=hip.EPI_H16, prec=BWD)
         # ---- MLP'                                                           (vision_encoder_utils.py:109-115,199)
         #      (dx16 = bf16 copy of dX, written by the LayerNorm' that produced dX)
-        hip.gemm(dx16, P["w_fc2_t"], None, dhid, epilogue=hip.EPI_H16_QGELU_BWD, prec=BWD, aux=pre)    # fc2^T, gelu' fused
+        hip.gemm(dx16, P["w_fc2_t"], None, dhid, epilogue=hip.EPI_H16_QGELU_BWD, prec=BWD, aux=pre, aux_prec=ACT)   # fc2^T, gelu' fused
         hip.gemm(dhid, P["w_fc1_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)
         hip.layernorm_backward(X1, ln2_g, dxn, dX, accumulate=True, dx16=dx16)
         # ---- attention'                                                     (vision_encoder_utils.py:61-81,190-191)
@@ -283,7 +311,7 @@ def vision_backward(model, saved, dcls_x, B, T, dsummary=None):
         hip.attention_backward(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dmix, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
                                batch=BT, heads=H, n=n1, prec=BWD, q_scale=0.125,
                                side_k=SIDEKV[:, :D], side_v=SIDEKV[:, D:], dside_k=dside[:, :D], dside_v=dside[:, D:],
-                               n_g=G, T=T, has_summary=True)
+                               n_g=G, T=T, has_summary=True, act_prec=ACT)
         hip.gemm(dqkv, P["w_qkv_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)
         # (norm1' of the main rows is applied at the end of the block, after the prompt path has added its share to
         #  the CLS rows of dX: it also writes the bf16 copy of the finished dX for the next block)
@@ -330,7 +358,7 @@ def vision_backward(model, saved, dcls_x, B, T, dsummary=None):
     grads["global_prompts"] = dgp
     # ---- ln_pre' and the temporal embedding (VitaCLIP_vision_encoder.py:86-100,108-113): time_embed[t] is added to
     #      every token of frame t
-    hip.layernorm_backward(saved[0], v.ln_pre.weight.detach().float().contiguous(), dX, dX)
+    hip.layernorm_backward(kept["e0"] if kept is not None else saved[0], v.ln_pre.weight.detach().float().contiguous(), dX, dX)
     grads["time_embed"] = dX.view(B, T, n1, D).sum(dim=(0, 2))
     return grads
 
@@ -344,19 +372,27 @@ class VisionTowerFn(torch.autograd.Function):
         sh = model._shape
         B, _, T = x.shape[:3]
         n1 = (sh["size"] // sh["P"]) ** 2 + 1
-        saved = torch.empty(sh["layers"] + 2, B * T * n1, sh["D"], dtype=torch.float32, device=x.device)
-        cls_x, summary = model.encode_video(x, saved=saved)
         fctx.model, fctx.BT = model, (B, T)
-        fctx.save_for_backward(saved)
+        if kept_bytes(model, B, T) <= model.keep_activation_bytes:
+            fctx.kept = alloc_kept(model, B, T, x.device)
+            cls_x, summary = model.encode_video(x, kept=fctx.kept)
+            fctx.save_for_backward()
+        else:
+            fctx.kept = None
+            saved = torch.empty(sh["layers"] + 2, B * T * n1, sh["D"], dtype=torch.float32, device=x.device)
+            cls_x, summary = model.encode_video(x, saved=saved)
+            fctx.save_for_backward(saved)
         return cls_x, summary
 
     @staticmethod
     def backward(fctx, dcls_x, dsummary):
-        (saved,) = fctx.saved_tensors
-        model = fctx.model
+        model, kept = fctx.model, fctx.kept
+        saved = fctx.saved_tensors[0] if kept is None else None
+        dev = (kept["x"] if kept is not None else saved).device
         if dcls_x is None:
-            dcls_x = torch.zeros(fctx.BT[0], model._shape["E"], device=saved.device)
-        g = vision_backward(model, saved, dcls_x.contiguous(), *fctx.BT, dsummary=dsummary)
+            dcls_x = torch.zeros(fctx.BT[0], model._shape["E"], device=dev)
+        g = vision_backward(model, saved, dcls_x.contiguous(), *fctx.BT, dsummary=dsummary, kept=kept)
+        fctx.kept = None      # release the activation buffers with the graph
         out = []
         for name, p in _vision_trainables(model):
             gi = g.get(name)

@@ -76,6 +76,10 @@ typedef struct {
    * [W_hi | W_hi | W_lo] (K' = 3K), i.e. A_hi W_hi + A_lo W_hi + A_hi W_lo in one pass. */
   int split_out;
   const void* aux;                  /* EPI_H16_QGELU_BWD: h16 pre-activations, rows as out (ld = ldo) */
+  int aux_prec;                     /* ... stored as GAVA_PREC_F16 / _BF16 (may differ from `prec`: activations kept
+                                     * from an fp16 forward, gradients in bf16) */
+  void* aux_out;                    /* EPI_H16_QGELU (training forward): also store the pre-activation acc + bias as
+                                     * h16 [M][ldo] here; NULL = off */
 } gava_gemm_args;
 int gava_gemm(const gava_gemm_args* a, gava_stream_t stream);
 
@@ -238,6 +242,8 @@ typedef struct {
   float* dside_k; float* dside_v; int64_t ld_dside;
   int n_g, T, has_summary, n_q;
   void* workspace;
+  int act_prec_set, act_prec;   /* vision path only: q/k/v/side_* are stored as act_prec (fp16 activations kept from the
+                                 * forward) while dout / dq / dk / dv use prec (bf16); 0 = same as prec */
 } gava_attention_bwd_args;
 int gava_attention_backward(const gava_attention_bwd_args* a, gava_stream_t stream);
 size_t gava_attention_backward_workspace_bytes(int batch, int heads, int n_q);
@@ -253,6 +259,18 @@ int gava_text_forward_train(const gava_text_model* m, const int32_t* tokens, con
 int gava_vision_forward_train(const gava_vision_model* m, const float* x, float* cls_x, float* summary,
                               float* debug_cls, float* saved_x, void* workspace, size_t workspace_bytes,
                               gava_stream_t stream);
+
+/* Training forward that keeps the backward's activations instead of leaving them to be recomputed.  With
+ * R = B*T_in*(n+1), SR = G + 2*B*T_in:  e0 fp32 [R][D] (embedding before ln_pre);  x fp32 [layers+1][R][D] (block inputs,
+ * last slot = final stream);  x1 fp32 [layers][R][D] (stream after the attention branch);  qkv h16 [layers][R][3D];
+ * pre h16 [layers][R][F] (fc1 output before QuickGELU);  sidekv h16 [layers][SR][2D] (prompt-row keys/values).
+ * Nothing is copied: the residual stream hops x[i] -> x1[i] -> x[i+1].  Every block runs in full. */
+typedef struct {
+  float* e0; float* x; float* x1; void* qkv; void* pre; void* sidekv;
+} gava_vision_saved;
+int gava_vision_forward_keep(const gava_vision_model* m, const float* x, float* cls_x, float* summary,
+                             const gava_vision_saved* saved, void* workspace, size_t workspace_bytes,
+                             gava_stream_t stream);
 
 /* Clip preprocessing of the evaluation data path (video_dataset/dataset.py:117-139, the
  * num_spatial_views = num_temporal_views = 1 case that every eval script uses): from the decoded RGB frames of

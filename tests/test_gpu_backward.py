@@ -169,13 +169,18 @@ def test_attention_backward_vision_with_prompt_rows_matches_autograd(BT, T, head
     (torch.stack(outs) * dout).sum().backward()
     qs = qkv.float().clone(); qs[:, :D] *= 0.125
     qd, sd_ = qs.bfloat16().cuda(), side.cuda()
+    act = None
+    if BT == 16 and T == 8:
+        # activations kept from an fp16 forward, gradients in bf16: the values are bf16-exact, so storing them as fp16 is
+        # lossless here and the result must be the same as in the all-bf16 case
+        qd, sd_, act = qd.half(), sd_.half(), hip.PREC_F16
     dqkv = torch.zeros(BT * n, 3 * D, dtype=torch.bfloat16, device="cuda")
     part = torch.empty(BT, G + T + 1, 2 * D, dtype=torch.float32, device="cuda")
     dside = part.view(-1, 2 * D)
     hip.attention_backward(qd[:, :D], qd[:, D:2 * D], qd[:, 2 * D:], do.cuda(), dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
                            batch=BT, heads=heads, n=n, prec=BF, q_scale=0.125,
                            side_k=sd_[:, :D], side_v=sd_[:, D:], dside_k=dside[:, :D], dside_v=dside[:, D:],
-                           n_g=G, T=T, has_summary=True, n_q=n_q)
+                           n_g=G, T=T, has_summary=True, n_q=n_q, act_prec=act)
     tol = 3 * 2 ** -8     # P and dS are rounded to bf16 between the two MFMA products (as P is in the forward kernel)
     ref_q = q32.grad.view(BT, n, D)[:, :nq]
     got_q = dqkv[:, :D].float().cpu().view(BT, n, D)[:, :nq]
@@ -284,12 +289,17 @@ def _check_against_reference_grads(m, gold, sampled=False):
     return worst
 
 
-def test_gradients_match_reference_tiny(golden_dir):
+@pytest.mark.parametrize("keep", [True, False])
+def test_gradients_match_reference_tiny(golden_dir, keep):
+    """keep=True: the forward keeps the per-block activations (gava_vision_forward_keep, fp16 activations + bf16
+    gradients in the backward); keep=False: the backward recomputes every block from its saved input."""
     import numpy as np, os
     gold = np.load(os.path.join(golden_dir, "tiny_grads.npz"))
     m = VitaCLIP(**model_kwargs(TINY, CLASSES_3))
     m.load_state_dict(synth_torch_state(TINY, 3), strict=True)
     m = m.cuda().train()
+    if not keep:
+        m.keep_activation_bytes = 0
     x = torch.from_numpy(synth.synth_clip(2, TINY.num_frames, TINY.input_size)).cuda()
     logits, lmt, lvm = m(x)
     assert lmt is None and lvm is None
