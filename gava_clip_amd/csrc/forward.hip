@@ -66,7 +66,7 @@ int gemm(const void* A, long lda, const void* W, long ldw, const float* bias, vo
 }
 
 struct VisionWs {
-  float* X; void* Xn; void* QKV; void* MIX; void* HID; void* PATCH;
+  float* X; void* Xn; void* QKV; void* MIX; void* HID;
   void* CLS16; float* CP; void* CPn; void* SQKV; void* SMIX; float* SUMM; void* SIDEn; void* SIDEKV;
   void* CLSPOST; float* PROJ;
   void* XNC; void* QC; void* MIXC; void* HIDC;   // last block: CLS rows only
@@ -84,9 +84,7 @@ VisionWs carve_vision(const gava_vision_model* m, void* ws, size_t cap) {
   w.Xn = c.take(R * D * 2);
   w.QKV = c.take(R * 3 * D * 2);
   w.MIX = c.take(R * D * 2);
-  const size_t hid = (size_t)R * F * 2, patch = (size_t)BT * n * patch_k(m) * 2;
-  w.HID = c.take(hid > patch ? hid : patch);
-  w.PATCH = w.HID;  // the patch matrix is dead before the first fc1
+  w.HID = c.take((size_t)R * F * 2);
   w.CLS16 = c.take(BT * D * 2);
   w.CP = (float*)c.take(BT * D * 4);
   w.CPn = c.take(BT * D * 2);

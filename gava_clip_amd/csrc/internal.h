@@ -4,7 +4,6 @@
 namespace gava {
 int side_ln(const float* gp, const float* lp, const float* cp, const float* summ, const float* gamma,
             const float* beta, void* out, int G, int T, int BT, int D, int prec, hipStream_t s);
-int patch_gather(const float* x, void* out, int B, int T, int S, int P, int Kp, int prec, hipStream_t s);
 int cls_embed(float* X, const float* cls, const float* pos, const float* time, int BT, int T, int D,
               long frame_stride, hipStream_t s);
 int mean_rows(const float* in, float* out, int B, int T, int D, hipStream_t s);

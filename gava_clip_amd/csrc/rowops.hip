@@ -137,43 +137,6 @@ __global__ __launch_bounds__(256) void side_ln_kernel(const SideParams p) {
     }
 }
 
-// ---- patch gather: x (B,3,T,S,S) fp32 -> patch matrix [BT*n][Kp] h16, k = (c,ky,kx), zero
-// padded to Kp.  One thread converts 4 consecutive kx (16 B read, 8 B write).
-template <class P>
-__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
-                                                           int B, int T, int S, int Pp, int Kp, long total4) {
-  const int g = S / Pp, n = g * g, K = 3 * Pp * Pp;
-  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total4; id += (long)gridDim.x * blockDim.x) {
-    const int k4 = (int)(id % (Kp / 4));
-    const long prow = id / (Kp / 4);
-    const int k = k4 * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < K) {
-      const int c = k / (Pp * Pp), rem = k - c * Pp * Pp, ky = rem / Pp, kx = rem - ky * Pp;
-      const int pp = (int)(prow % n);
-      const long frame = prow / n;
-      const int b = (int)(frame / T), t = (int)(frame % T);
-      const int py = pp / g, px = pp - py * g;
-      const float* src = x + ((((long)b * 3 + c) * T + t) * S + (py * Pp + ky)) * S + px * Pp + kx;
-      if ((Pp & 3) == 0) {
-        v = *reinterpret_cast<const float4*>(src);
-      } else {  // patch width not a multiple of 4 (P=14): 4 k's may wrap to the next ky row
-        float e[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int kj = k + j;
-          if (kj < K) {
-            const int cj = kj / (Pp * Pp), rj = kj - cj * Pp * Pp, kyj = rj / Pp, kxj = rj - kyj * Pp;
-            e[j] = x[((((long)b * 3 + cj) * T + t) * S + (py * Pp + kyj)) * S + px * Pp + kxj];
-          } else e[j] = 0.f;
-        }
-        v = make_float4(e[0], e[1], e[2], e[3]);
-      }
-    }
-    store_h16x4<P>(out + prow * Kp + k, v);
-  }
-}
-
 // cls rows of the embedding: X[frame*(n+1)] = cls_token + pos[0] + time[frame % T]
 __global__ void cls_embed_kernel(float* X, const float* cls, const float* pos, const float* time,
                                  int BT, int T, int D, long frame_stride) {
@@ -355,16 +318,6 @@ int side_ln(const float* gp, const float* lp, const float* cp, const float* summ
   const int rows = G + 2 * BT;
   if (prec == GAVA_PREC_F16) hipLaunchKernelGGL(side_ln_kernel<PrecF16>, dim3((rows + 3) / 4), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(side_ln_kernel<PrecBF16>, dim3((rows + 3) / 4), dim3(256), 0, s, p);
-  GAVA_CHECK_LAUNCH();
-  return GAVA_OK;
-}
-
-int patch_gather(const float* x, void* out, int B, int T, int S, int P, int Kp, int prec, hipStream_t s) {
-  const int g = S / P;
-  const long total4 = (long)B * T * g * g * (Kp / 4);
-  const int blocks = (int)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
-  if (prec == GAVA_PREC_F16) hipLaunchKernelGGL(patch_gather_kernel<PrecF16>, dim3(blocks), dim3(256), 0, s, x, (unsigned short*)out, B, T, S, P, Kp, total4);
-  else hipLaunchKernelGGL(patch_gather_kernel<PrecBF16>, dim3(blocks), dim3(256), 0, s, x, (unsigned short*)out, B, T, S, P, Kp, total4);
   GAVA_CHECK_LAUNCH();
   return GAVA_OK;
 }
