@@ -46,7 +46,8 @@ struct GemmParams {
   int split_out;
   int sm, sn;   // super-tile shape (in tiles)
   unsigned long long* dbg;  // debug only: per-wave segment cycle sums (gava_debug_set_buffer)
-  int ablate;   // debug only (GAVA_GEMM_ABLATE): 1 = no staging loads after the prologue, 2 = no LDS reads/MFMA
+  int ablate;   // timing probes, always 0 unless built with -DGAVA_ENABLE_ABLATE: 1 = no staging loads after the prologue,
+                // 2 = no LDS reads/MFMA, 4 = no epilogue
 };
 
 static __device__ __forceinline__ float aux_up(unsigned short u, int f16) {
@@ -1023,8 +1024,12 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.pos = a->pos; gp.time = a->time; gp.n_patches = a->n_patches; gp.T = a->T;
   gp.frames = patch_direct ? a->frames : nullptr; gp.fsize = a->frame_size; gp.patch = a->patch;
   gp.split_out = a->split_out;
+#ifdef GAVA_ENABLE_ABLATE   // timing-probe builds only (tools/ab_build.sh NAME -DGAVA_ENABLE_ABLATE): results are WRONG by design
   static const int ablate = getenv("GAVA_GEMM_ABLATE") ? atoi(getenv("GAVA_GEMM_ABLATE")) : 0;
   gp.ablate = ablate;
+#else
+  gp.ablate = 0;
+#endif
   gp.dbg = gava::debug_buffer();
   hipStream_t s = (hipStream_t)stream;
   if (a->prec == GAVA_PREC_F16) return launch_prec<PrecF16>(gp, a->epilogue, s);
