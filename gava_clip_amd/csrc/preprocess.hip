@@ -64,8 +64,12 @@ extern "C" int gava_preprocess_clip(const gava_preprocess_args* a, gava_stream_t
   else { p.new_h = (int)((long)a->height * a->size / a->width); p.new_w = a->size; }
   if (p.new_h < a->size || p.new_w < a->size) return GAVA_EINVAL;   // dataset.py:182 asserts the same
   p.h_st = (p.new_h - a->size) / 2; p.w_st = (p.new_w - a->size) / 2;
+  if (a->first_spatial_view) {   // dataset.py:188-199: three crops along the long side, the first at offset 0
+    if (p.new_h != a->size && p.new_w != a->size) return GAVA_EINVAL;   // upstream asserts min side == size
+    p.h_st = 0; p.w_st = 0;
+  }
   const int seg = (a->T - 1) * a->rate + 1;
-  p.t_st = a->n_frames > seg ? (a->n_frames - seg) / 2 : 0;
+  p.t_st = (a->n_frames > seg && !a->first_temporal_view) ? (a->n_frames - seg) / 2 : 0;
   p.scale_h = (float)a->height / (float)p.new_h;
   p.scale_w = (float)a->width / (float)p.new_w;
   for (int c = 0; c < 3; ++c) { p.mean[c] = a->mean[c]; p.std[c] = a->std[c]; }

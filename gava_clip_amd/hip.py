@@ -84,7 +84,8 @@ class PreprocessArgs(C.Structure):
     _fields_ = [("frames", _vp), ("n_frames", C.c_int), ("height", C.c_int), ("width", C.c_int),
                 ("mean", C.c_float * 3), ("std", C.c_float * 3),
                 ("T", C.c_int), ("rate", C.c_int), ("size", C.c_int),
-                ("out", _fp), ("out_stride_c", C.c_int64), ("out_stride_t", C.c_int64)]
+                ("out", _fp), ("out_stride_c", C.c_int64), ("out_stride_t", C.c_int64),
+                ("first_temporal_view", C.c_int), ("first_spatial_view", C.c_int)]
 
 
 class VisionSaved(C.Structure):
@@ -249,7 +250,7 @@ def convert_h16(x, prec):
     return out
 
 
-def preprocess_clip(frames_u8, out, *, T, rate, size, mean, std):
+def preprocess_clip(frames_u8, out, *, T, rate, size, mean, std, first_temporal_view=False, first_spatial_view=False):
     """frames_u8: uint8 [n][H][W][3] (device); out: fp32 view [3][T][size][size] whose last two dims are contiguous."""
     assert frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.shape[-1] == 3 and frames_u8.is_contiguous()
     assert out.dtype == torch.float32 and tuple(out.shape) == (3, T, size, size)
@@ -259,6 +260,7 @@ def preprocess_clip(frames_u8, out, *, T, rate, size, mean, std):
     a.mean, a.std = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
     a.T, a.rate, a.size = T, rate, size
     a.out, a.out_stride_c, a.out_stride_t = ptr(out), out.stride(0), out.stride(1)
+    a.first_temporal_view, a.first_spatial_view = int(first_temporal_view), int(first_spatial_view)
     check(load().gava_preprocess_clip(C.byref(a), stream_ptr()), "gava_preprocess_clip")
 
 

@@ -17,15 +17,18 @@ CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
 class ClipPreprocessor:
-    """Mirror of VideoDataset(random_sample=False, num_spatial_views=1, num_temporal_views=1, ...).
+    """Mirror of VideoDataset(random_sample=False, ...) (the evaluation branch, any view counts upstream accepts).
 
     Same argument names as the reference constructor (dataset.py:23-33) for the ones that matter here.
     """
 
     def __init__(self, num_frames=8, sampling_rate=1, spatial_size=224, mean=CLIP_MEAN, std=CLIP_STD,
                  num_spatial_views=1, num_temporal_views=1):
-        if num_spatial_views != 1 or num_temporal_views != 1:
-            raise NotImplementedError("multi-view evaluation crops (dataset.py:188-199) are host-side only")
+        if num_spatial_views not in (1, 3):
+            raise NotImplementedError()          # dataset.py:201-202
+        # upstream builds all num_spatial_views x num_temporal_views crops but returns only the first one
+        # (`frames = frames[0]`, dataset.py:134-139): the top/left spatial crop and the temporal crop starting at frame 0
+        self.num_spatial_views, self.num_temporal_views = num_spatial_views, num_temporal_views
         self.num_frames, self.sampling_rate, self.spatial_size = num_frames, sampling_rate, spatial_size
         self.mean = tuple(float(v) for v in torch.as_tensor(mean).flatten().tolist())
         self.std = tuple(float(v) for v in torch.as_tensor(std).flatten().tolist())
@@ -38,7 +41,10 @@ class ClipPreprocessor:
         h, w = frames.shape[1], frames.shape[2]
         s = self.spatial_size
         new_h, new_w = (s, w * s // h) if h < w else (h * s // w, s)
-        assert min(new_h, new_w) >= s   # dataset.py:182
+        if self.num_spatial_views == 1:
+            assert min(new_h, new_w) >= s   # dataset.py:182
+        else:
+            assert min(new_h, new_w) == s   # dataset.py:189
 
     def __call__(self, frames, out=None):
         """frames: uint8 [n, H, W, 3] on the GPU -> fp32 [3, T, S, S] (dataset.py returns frames[0] of this shape)."""
@@ -46,7 +52,8 @@ class ClipPreprocessor:
         T, S = self.num_frames, self.spatial_size
         if out is None:
             out = torch.empty(3, T, S, S, dtype=torch.float32, device=frames.device)
-        hip.preprocess_clip(frames.contiguous(), out, T=T, rate=self.sampling_rate, size=S, mean=self.mean, std=self.std)
+        hip.preprocess_clip(frames.contiguous(), out, T=T, rate=self.sampling_rate, size=S, mean=self.mean, std=self.std,
+                            first_temporal_view=self.num_temporal_views > 1, first_spatial_view=self.num_spatial_views == 3)
         return out
 
     def batch(self, videos):

@@ -288,6 +288,10 @@ typedef struct {
   float mean[3], std[3];
   int T, rate, size;
   float* out; int64_t out_stride_c, out_stride_t;
+  /* the dataset returns only the FIRST of its num_spatial_views x num_temporal_views crops (`frames = frames[0]`,
+   * :136-139): with more than one temporal view that is the crop starting at frame 0 (:171-172), with three spatial
+   * views the top / left one (:188-199).  first_temporal_view / first_spatial_view != 0 select those; 0 = centred. */
+  int first_temporal_view, first_spatial_view;
 } gava_preprocess_args;
 int gava_preprocess_clip(const gava_preprocess_args* a, gava_stream_t stream);
 

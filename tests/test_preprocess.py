@@ -89,3 +89,16 @@ def test_gpu_preprocess_rejects_host_tensor_and_small_frames():
     pre = ClipPreprocessor()
     with pytest.raises(hip.GavaError):
         pre(_video(8, 240, 320, 3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,h,w,views", [(30, 240, 320, (1, 10)), (30, 320, 240, (3, 10)), (12, 224, 400, (3, 1))])
+def test_gpu_preprocess_first_of_many_views(n, h, w, views):
+    """evaluate.py's defaults (--num_temporal_views 10): upstream builds every crop and returns the first."""
+    from gava_clip_amd.preprocess import ClipPreprocessor
+    v = _video(n, h, w, n + h)
+    ref = po.preprocess_clip(v, 8, 2, 224, MEAN, STD, num_spatial_views=views[0], num_temporal_views=views[1])
+    pre = ClipPreprocessor(num_frames=8, sampling_rate=2, spatial_size=224, mean=MEAN, std=STD,
+                           num_spatial_views=views[0], num_temporal_views=views[1])
+    got = pre(v.cuda()).cpu()
+    assert (got - ref).abs().max().item() <= 6e-6
