@@ -407,3 +407,29 @@ def test_optimizer_steps_refresh_only_trainable_copies_and_match_a_fresh_model()
         # not bit-for-bit: d gamma / d beta of summary_ln are accumulated with fp32 atomics (order varies run to run)
         for (n, p), (_, q) in zip(m.named_parameters(), fresh.named_parameters()):
             assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), (step, n)
+
+
+def test_seventy_frame_clips_forward_and_backward_match_oracle():
+    """train_scripts/updrs_3cls_train_tulip.sh trains with --num_frames 70: 70 local-prompt rows per frame, a 70-token
+    summary attention (small backward kernel at n = 70), 96-key tiles in the main attention backward."""
+    import dataclasses
+    cfg = dataclasses.replace(TINY, num_frames=70)
+    sd = synth_torch_state(cfg, 3)
+    m = VitaCLIP(**model_kwargs(cfg, CLASSES_3))
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    x = torch.from_numpy(synth.synth_clip(1, 70, cfg.input_size))
+    wlog = torch.randn(1, 3, generator=torch.Generator().manual_seed(9))
+    ref_logits, ref = _oracle_all_grads(cfg, sd, torch.cat(m.tokenized_prompts).cpu(), x, wlog)
+    logits = m(x.cuda())[0]
+    assert (logits.detach().cpu() - ref_logits).abs().max() <= 1e-3 * ref_logits.abs().max()
+    (logits * wlog.cuda()).sum().backward()
+    got = {n: p.grad for n, p in m.named_parameters()}
+    bad = {}
+    for name, g_ref in ref.items():
+        if name.endswith("k_proj.bias"):
+            continue
+        r = rel(got[name].cpu(), g_ref)
+        if r > 4e-2:
+            bad[name] = r
+    assert not bad, bad
