@@ -249,6 +249,21 @@ def main():
                            "achieved": fc1["tflops"], "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(fc1["tflops"] / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
                            "flops_per_launch": fc1["flops"], "ms_per_launch": fc1["ms"]}
+    if rank == 0 and not a.no_kernels:
+        # yardstick, not a target: the vendor library (torch.matmul -> hipBLASLt) on the roofline kernel's shape, plain
+        # GEMM with 16-bit output and NO bias / QuickGELU epilogue
+        try:
+            dt_ = torch.float16 if a.prec == "fp16" else torch.bfloat16
+            Mv, Nv, Kv = B * cfg.num_frames * cfg.tokens_main, cfg.mlp_dim, cfg.feature_dim
+            Av = torch.randn(Mv, Kv, device="cuda", dtype=dt_)
+            Wv = torch.randn(Nv, Kv, device="cuda", dtype=dt_) * Kv ** -0.5
+            Ov = torch.empty(Mv, Nv, device="cuda", dtype=dt_)
+            msv = event_time_ms(lambda: torch.matmul(Av, Wv.t(), out=Ov), iters=10, warmup=5)
+            out["vendor_yardstick"] = {"what": "torch.matmul (hipBLASLt) on the fc1 shape, no epilogue", "ms": round(msv, 4),
+                                       "tflops": round(2.0 * Mv * Nv * Kv / msv / 1e9, 1)}
+            del Av, Wv, Ov
+        except Exception as e:   # the yardstick must never break the bench line
+            log(f"vendor yardstick skipped: {e}")
     if rank == 0 and not a.no_alt:
         log("alt operand dtype run")
         other = "bf16" if a.prec == "fp16" else "fp16"
