@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const gava::AttnBwd
   for (int qt = wave; qt < n_qt; qt += 4) {
     const int qi = qt * 16 + fr;
     const int qrow = qi < p.n_q ? qi : p.n_q - 1;
-    const unsigned short* qp = p.q + (row0 + qrow) * p.ld_qkv + h * 64 + 8 * fg;
-    const unsigned short* op = p.dout + (row0 + qrow) * p.ld_dout + h * 64 + 8 * fg;
+    const long qrow0 = (long)n * p.q_rows;   // query-side buffers (q, dout, dq) may hold fewer rows per frame
+    const unsigned short* qp = p.q + (qrow0 + qrow) * p.ld_q + h * 64 + 8 * fg;
+    const unsigned short* op = p.dout + (qrow0 + qrow) * p.ld_dout + h * 64 + 8 * fg;
     const s16x8_t q0 = load_act8<PA, P>(qp), q1 = load_act8<PA, P>(qp + 32);
     const s16x8_t g0 = *reinterpret_cast<const s16x8_t*>(op), g1 = *reinterpret_cast<const s16x8_t*>(op + 32);
 
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const gava::AttnBwd
       }
     }
     if (qi < p.n_q) {
-      unsigned short* dq = p.dq + (row0 + qi) * p.ld_dqkv + h * 64 + 4 * fg;
+      unsigned short* dq = p.dq + (qrow0 + qi) * p.ld_dq + h * 64 + 4 * fg;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         *reinterpret_cast<uint2*>(dq + dt * 16) = pack4<P>(o[dt][0] * p.q_scale, o[dt][1] * p.q_scale, o[dt][2] * p.q_scale, o[dt][3] * p.q_scale);
@@ -247,8 +248,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const gava::AttnBw
       const int id = tid + it * 256;
       const int row = id >> 3, chunk = id & 7;
       const int rowc = row < p.n_q ? row : 0;
-      qv[it] = *reinterpret_cast<const uint4*>(p.q + (row0 + rowc) * p.ld_qkv + h * 64 + chunk * 8);
-      ov[it] = *reinterpret_cast<const uint4*>(p.dout + (row0 + rowc) * p.ld_dout + h * 64 + chunk * 8);
+      qv[it] = *reinterpret_cast<const uint4*>(p.q + ((long)n * p.q_rows + rowc) * p.ld_q + h * 64 + chunk * 8);
+      ov[it] = *reinterpret_cast<const uint4*>(p.dout + ((long)n * p.q_rows + rowc) * p.ld_dout + h * 64 + chunk * 8);
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {

@@ -262,6 +262,11 @@ extern "C" int gava_attention_backward(const gava_attention_bwd_args* a, gava_st
   p.sk = (const unsigned short*)a->side_k; p.sv = (const unsigned short*)a->side_v; p.ld_side = a->ld_side;
   p.dout = (const unsigned short*)a->dout; p.ld_dout = a->ld_dout;
   p.dq = (unsigned short*)a->dq; p.dk = (unsigned short*)a->dk; p.dv = (unsigned short*)a->dv; p.ld_dqkv = a->ld_dqkv;
+  // separate query-side buffers (the CLS-only last block): q_batch_rows rows per frame, own strides
+  p.q_rows = a->q_batch_rows ? a->q_batch_rows : a->n;
+  p.ld_q = a->q_batch_rows ? a->ld_q : a->ld_qkv;
+  p.ld_dq = a->q_batch_rows ? a->ld_dq : a->ld_dqkv;
+  if (a->q_batch_rows && (a->ld_q % 8 || a->ld_dq % 4 || a->q_batch_rows < (a->n_q ? a->n_q : a->n))) return GAVA_EINVAL;
   p.dsk = a->dside_k; p.dsv = a->dside_v; p.ld_dside = a->ld_dside;
   p.stats = (float*)a->workspace;
   p.batch = a->batch; p.heads = a->heads; p.n_q = a->n_q ? a->n_q : a->n; p.n_kmain = a->n;

@@ -255,7 +255,7 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
 // (288 GB of HBM: ~21 GB at c2).  Nothing is copied: the residual stream hops from buffer to buffer
 // (x[i] -> x1[i] -> x[i+1], the GEMMs' residual input and output being different pointers), the QKV GEMM and the prompt
 // path write straight into the per-block slots, and fc1 stores its pre-activation beside the QuickGELU output.
-// Every block runs in full (no CLS-only shortcut in the last one: its keys/values need gradients anyway).
+// With last_q / last_x1 / last_pre the last block runs on the CLS rows only, like the inference driver.
 extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float* x, float* cls_x, float* summary,
                                         const gava_vision_saved* sv, void* workspace, size_t workspace_bytes,
                                         gava_stream_t stream) {
@@ -313,6 +313,32 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
     if (two && hipEventRecord(g_side.join[i], g_side.s) != hipSuccess) return GAVA_ELAUNCH;
     gava::set_gemm_cu_reserve(two ? 8 : 0);
     TRY(ln(Xin, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
+    if (i + 1 == m->layers && sv->last_q && sv->last_x1 && sv->last_pre) {
+      // Last block, as in the inference driver: keys/values for every row, queries / out_proj / MLP for the B*T CLS
+      // rows only (VitaCLIP_vision_encoder.py:126 reads x[:,0]).  Kept: K/V in the QKV slot, the CLS queries, the CLS
+      // rows of the stream after attention, the CLS pre-activations.
+      unsigned short* QC = (unsigned short*)sv->last_q;
+      unsigned short* PREC = (unsigned short*)sv->last_pre;
+      TRY(gemm(w.Xn, D, wqkv + (long)D * D, D, L.b_qkv + D, QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream));
+      TRY(gemm(w.Xn, fs, L.w_qkv, D, L.b_qkv, QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+      gava::set_gemm_cu_reserve(0);
+      if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
+      {
+        gava_attention_args a{};
+        a.q = QC; a.ld_q = D; a.q_batch_rows = 1;
+        a.k = QKV + D; a.v = QKV + 2 * D; a.ld_qkv = 3 * D;
+        a.side_k = SKV; a.side_v = SKV + D; a.ld_side = 2 * D;
+        a.out = w.MIXC; a.ld_out = D;
+        a.batch = BT; a.heads = m->H; a.n_q = 1; a.n_kmain = n + 1;
+        a.n_g = G; a.T = Tm; a.has_summary = 1; a.prec = pr;
+        TRY(gava_attention(&a, stream));
+      }
+      TRY(gemm(w.MIXC, D, L.w_out, D, L.b_out, sv->last_x1, D, BT, D, D, GAVA_EPI_F32, pr, stream, Xin, fs));
+      TRY(ln(sv->last_x1, D, nullptr, L.ln2_g, L.ln2_b, w.XNC, D, nullptr, 0, BT, D, pr, stream));
+      TRY(gemm(w.XNC, D, L.w_fc1, D, L.b_fc1, w.HIDC, F, BT, F, D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, 0, PREC));
+      TRY(gemm(w.HIDC, F, L.w_fc2, F, L.b_fc2, Xout, fs, BT, D, F, GAVA_EPI_F32, pr, stream, sv->last_x1, D));
+      continue;
+    }
     TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
     gava::set_gemm_cu_reserve(0);
     if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;

@@ -15,6 +15,7 @@ unsigned long long* debug_buffer();
 // MFMA attention backward (attention_bwd.hip), launched by gava_attention_backward (backward.hip)
 struct AttnBwdMfmaParams {
   const unsigned short* q; const unsigned short* k; const unsigned short* v; long ld_qkv;
+  long ld_q, ld_dq; int q_rows;  // query-side layout: rows per frame in q / dout / dq and their strides
   const unsigned short* sk; const unsigned short* sv; long ld_side;
   const unsigned short* dout; long ld_dout;
   unsigned short* dq; unsigned short* dk; unsigned short* dv; long ld_dqkv;

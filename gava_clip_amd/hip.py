@@ -89,7 +89,8 @@ class PreprocessArgs(C.Structure):
 
 
 class VisionSaved(C.Structure):
-    _fields_ = [("e0", _fp), ("x", _fp), ("x1", _fp), ("qkv", _vp), ("pre", _vp), ("sidekv", _vp)]
+    _fields_ = [("e0", _fp), ("x", _fp), ("x1", _fp), ("qkv", _vp), ("pre", _vp), ("sidekv", _vp),
+                ("last_q", _vp), ("last_x1", _fp), ("last_pre", _vp)]
 
 
 class LayerNormBwdArgs(C.Structure):
@@ -108,7 +109,8 @@ class AttentionBwdArgs(C.Structure):
                 ("side_k", _vp), ("side_v", _vp), ("ld_side", C.c_int64),
                 ("dside_k", _fp), ("dside_v", _fp), ("ld_dside", C.c_int64),
                 ("n_g", C.c_int), ("T", C.c_int), ("has_summary", C.c_int), ("n_q", C.c_int), ("workspace", _vp),
-                ("act_prec_set", C.c_int), ("act_prec", C.c_int)]
+                ("act_prec_set", C.c_int), ("act_prec", C.c_int),
+                ("q_batch_rows", C.c_int), ("ld_q", C.c_int64), ("ld_dq", C.c_int64)]
 
 
 _lib = None
@@ -285,8 +287,9 @@ def qgelu_backward(pre, dh, dpre, prec):
 
 def attention_backward(q, k, v, dout, dq, dk, dv, *, batch, heads, n, prec, causal=False, q_scale=1.0,
                        side_k=None, side_v=None, dside_k=None, dside_v=None, n_g=0, T=0, has_summary=False, n_q=0,
-                       act_prec=None):
+                       act_prec=None, q_batch_rows=0):
     a = AttentionBwdArgs()
+    a.q_batch_rows, a.ld_q, a.ld_dq = q_batch_rows, (q.stride(0) if q_batch_rows else 0), (dq.stride(0) if q_batch_rows else 0)
     a.act_prec_set, a.act_prec = int(act_prec is not None), (act_prec if act_prec is not None else prec)
     a.side_k, a.side_v = ptr(side_k), ptr(side_v)
     a.ld_side = side_k.stride(0) if side_k is not None else 0
@@ -297,8 +300,8 @@ def attention_backward(q, k, v, dout, dq, dk, dv, *, batch, heads, n, prec, caus
     if side_k is not None or n > 88:
         ws = torch.empty(load().gava_attention_backward_workspace_bytes(batch, heads, n_q or n), dtype=torch.uint8, device=q.device)
     a.workspace = ptr(ws)
-    a.q, a.k, a.v, a.ld_qkv = ptr(q), ptr(k), ptr(v), q.stride(0)
+    a.q, a.k, a.v, a.ld_qkv = ptr(q), ptr(k), ptr(v), k.stride(0)
     a.dout, a.ld_dout = ptr(dout), dout.stride(0)
-    a.dq, a.dk, a.dv, a.ld_dqkv = ptr(dq), ptr(dk), ptr(dv), dq.stride(0)
+    a.dq, a.dk, a.dv, a.ld_dqkv = ptr(dq), ptr(dk), ptr(dv), dk.stride(0)
     a.batch, a.heads, a.n, a.causal, a.prec, a.q_scale = batch, heads, n, int(causal), prec, q_scale
     check(load().gava_attention_backward(C.byref(a), stream_ptr()), "gava_attention_backward")

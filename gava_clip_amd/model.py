@@ -593,7 +593,8 @@ class VitaCLIP(nn.Module):
         dbg = torch.empty(sh["layers"], B * T, sh["D"], dtype=torch.float32, device=x.device) if self.debug_taps else None
         if kept is not None:
             sv = hip.VisionSaved(hip.ptr(kept["e0"]), hip.ptr(kept["x"]), hip.ptr(kept["x1"]), hip.ptr(kept["qkv"]),
-                                 hip.ptr(kept["pre"]), hip.ptr(kept["sidekv"]))
+                                 hip.ptr(kept["pre"]), hip.ptr(kept["sidekv"]), hip.ptr(kept.get("last_q")),
+                                 hip.ptr(kept.get("last_x1")), hip.ptr(kept.get("last_pre")))
             hip.check(lib.gava_vision_forward_keep(C.byref(m), hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), C.byref(sv),
                                                    hip.ptr(ws), ws.numel(), hip.stream_ptr()), "gava_vision_forward_keep")
         else:

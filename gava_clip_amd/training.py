@@ -213,7 +213,7 @@ def kept_bytes(model, B, T):
     sh = model._shape
     n1 = (sh["size"] // sh["P"]) ** 2 + 1
     R, D, F, NL = B * T * n1, sh["D"], sh["F"], sh["layers"]
-    return R * D * 4 * (2 * NL + 2) + NL * (R * 3 * D * 2 + R * F * 2 + (sh["G"] + 2 * B * T) * 2 * D * 2)
+    return R * D * 4 * (2 * NL + 1) + NL * R * 3 * D * 2 + (NL - 1) * R * F * 2 + NL * (sh["G"] + 2 * B * T) * 2 * D * 2
 
 
 def alloc_kept(model, B, T, device):
@@ -223,8 +223,11 @@ def alloc_kept(model, B, T, device):
     R, D, F, NL, SR = B * T * n1, sh["D"], sh["F"], sh["layers"], sh["G"] + 2 * B * T
     h16 = hip.h16_dtype(model.prec)
     e = lambda *s, dtype=torch.float32: torch.empty(*s, dtype=dtype, device=device)
-    return dict(e0=e(R, D), x=e(NL + 1, R, D), x1=e(NL, R, D), qkv=e(NL, R, 3 * D, dtype=h16), pre=e(NL, R, F, dtype=h16),
-                sidekv=e(NL, SR, 2 * D, dtype=h16))
+    BT = B * T
+    return dict(e0=e(R, D), x=e(NL + 1, R, D), x1=e(max(NL - 1, 1), R, D), qkv=e(NL, R, 3 * D, dtype=h16),
+                pre=e(max(NL - 1, 1), R, F, dtype=h16), sidekv=e(NL, SR, 2 * D, dtype=h16),
+                # the last block runs on the CLS rows only (as in inference): its CLS queries / stream / pre-activations
+                last_q=e(BT, D, dtype=h16), last_x1=e(BT, D), last_pre=e(BT, F, dtype=h16))
 
 
 def vision_backward(model, saved, dcls_x, B, T, dsummary=None, kept=None):
@@ -283,7 +286,10 @@ def vision_backward(model, saved, dcls_x, B, T, dsummary=None, kept=None):
         hip.gemm(SMIX, P["w_sout"], f32(s.out_proj.bias), SUMM, epilogue=hip.EPI_F32, prec=BWD, resid=CP)
         lp = blk.local_prompts.detach().float()[0]                                     # (T, D)
         SIDE = torch.cat([v.global_prompts.detach().float()[i], (CP.view(B, T, D) + lp).view(BT, D), SUMM], 0).contiguous()
-        if kept is not None:
+        cls_only = kept is not None and i == NL - 1 and "last_q" in kept
+        if cls_only:
+            SIDEKV, qkv = kept["sidekv"][i], kept["qkv"][i]
+        elif kept is not None:
             SIDEKV, qkv, X1, pre = kept["sidekv"][i], kept["qkv"][i], kept["x1"][i], kept["pre"][i]
         else:
             SIDEn = new(SR, D)
@@ -299,20 +305,41 @@ def vision_backward(model, saved, dcls_x, B, T, dsummary=None, kept=None):
             hip.gemm(mix, P["w_out"], P["b_out"], X1, epilogue=hip.EPI_F32, prec=BWD, resid=X0)
             hip.layernorm(X1, ln2_g, ln2_b, out16=xn, prec=BWD)
             hip.gemm(xn, P["w_fc1"], P["b_fc1"], pre, epilogue=hip.EPI_H16, prec=BWD)
-        # ---- MLP'                                                           (vision_encoder_utils.py:109-115,199)
-        #      (dx16 = bf16 copy of dX, written by the LayerNorm' that produced dX)
-        hip.gemm(dx16, P["w_fc2_t"], None, dhid, epilogue=hip.EPI_H16_QGELU_BWD, prec=BWD, aux=pre, aux_prec=ACT)   # fc2^T, gelu' fused
-        hip.gemm(dhid, P["w_fc1_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)
-        hip.layernorm_backward(X1, ln2_g, dxn, dX, accumulate=True, dx16=dx16)
-        # ---- attention'                                                     (vision_encoder_utils.py:61-81,190-191)
-        hip.gemm(dx16, P["w_out_t"], None, dmix, epilogue=hip.EPI_H16, prec=BWD)
         part = new(BT, G + T + 1, 2 * D, dtype=torch.float32)     # per-frame partials of the shared prompt rows
         dside = part.view(BT * (G + T + 1), 2 * D)
-        hip.attention_backward(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dmix, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
-                               batch=BT, heads=H, n=n1, prec=BWD, q_scale=0.125,
-                               side_k=SIDEKV[:, :D], side_v=SIDEKV[:, D:], dside_k=dside[:, :D], dside_v=dside[:, D:],
-                               n_g=G, T=T, has_summary=True, act_prec=ACT)
-        hip.gemm(dqkv, P["w_qkv_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)
+        if cls_only:
+            # last block: only the CLS rows carry a gradient (VitaCLIP_vision_encoder.py:126) - MLP', out_proj' and the
+            # query side of attention' on B*T rows; keys / values (and through them every row of the block input) in full
+            dXc = dX.view(BT, n1, D)[:, 0].contiguous()
+            dxc16 = hip.convert_h16(dXc, BWD)
+            dhid_c = new(BT, F)
+            hip.gemm(dxc16, P["w_fc2_t"], None, dhid_c, epilogue=hip.EPI_H16_QGELU_BWD, prec=BWD, aux=kept["last_pre"], aux_prec=ACT)
+            dxn_c = new(BT, D, dtype=torch.float32)
+            hip.gemm(dhid_c, P["w_fc1_t"], None, dxn_c, epilogue=hip.EPI_F32, prec=BWD)
+            hip.layernorm_backward(kept["last_x1"], ln2_g, dxn_c, dXc, accumulate=True, dx16=dxc16)
+            dmix_c, dq_c = new(BT, D), new(BT, D)
+            hip.gemm(dxc16, P["w_out_t"], None, dmix_c, epilogue=hip.EPI_H16, prec=BWD)
+            hip.attention_backward(kept["last_q"], qkv[:, D:2 * D], qkv[:, 2 * D:], dmix_c, dq_c, dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                                   batch=BT, heads=H, n=n1, prec=BWD, q_scale=0.125,
+                                   side_k=SIDEKV[:, :D], side_v=SIDEKV[:, D:], dside_k=dside[:, :D], dside_v=dside[:, D:],
+                                   n_g=G, T=T, has_summary=True, act_prec=ACT, n_q=1, q_batch_rows=1)
+            hip.gemm(dqkv[:, D:], P["w_kv_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)          # [dK dV] . [Wk; Wv]
+            dxn_cls = dxn.view(BT, n1 * D)[:, :D]                                                     # CLS rows, stride n1*D
+            hip.gemm(dq_c, P["w_qkv_t"][:, :D], None, dxn_cls, epilogue=hip.EPI_F32, prec=BWD, resid=dxn_cls)   # + dQ . Wq
+            dX.view(BT, n1, D)[:, 0] = dXc
+        else:
+            # ---- MLP'                                                       (vision_encoder_utils.py:109-115,199)
+            #      (dx16 = bf16 copy of dX, written by the LayerNorm' that produced dX)
+            hip.gemm(dx16, P["w_fc2_t"], None, dhid, epilogue=hip.EPI_H16_QGELU_BWD, prec=BWD, aux=pre, aux_prec=ACT)   # fc2^T, gelu' fused
+            hip.gemm(dhid, P["w_fc1_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)
+            hip.layernorm_backward(X1, ln2_g, dxn, dX, accumulate=True, dx16=dx16)
+            # ---- attention'                                                 (vision_encoder_utils.py:61-81,190-191)
+            hip.gemm(dx16, P["w_out_t"], None, dmix, epilogue=hip.EPI_H16, prec=BWD)
+            hip.attention_backward(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dmix, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                                   batch=BT, heads=H, n=n1, prec=BWD, q_scale=0.125,
+                                   side_k=SIDEKV[:, :D], side_v=SIDEKV[:, D:], dside_k=dside[:, :D], dside_v=dside[:, D:],
+                                   n_g=G, T=T, has_summary=True, act_prec=ACT)
+            hip.gemm(dqkv, P["w_qkv_t"], None, dxn, epilogue=hip.EPI_F32, prec=BWD)
         # (norm1' of the main rows is applied at the end of the block, after the prompt path has added its share to
         #  the CLS rows of dX: it also writes the bf16 copy of the finished dX for the next block)
         # ---- prompt rows': sum the partials over the frames that share a row (global: all; local: the T frames of the

@@ -244,6 +244,9 @@ typedef struct {
   void* workspace;
   int act_prec_set, act_prec;   /* vision path only: q/k/v/side_* are stored as act_prec (fp16 activations kept from the
                                  * forward) while dout / dq / dk / dv use prec (bf16); 0 = same as prec */
+  int q_batch_rows; int64_t ld_q, ld_dq; /* vision path, != 0: q, dout and dq are separate buffers holding q_batch_rows rows
+                                 * per frame (strides ld_q, ld_dout, ld_dq), as gava_attention's q_batch_rows: the CLS-only
+                                 * last block */
 } gava_attention_bwd_args;
 int gava_attention_backward(const gava_attention_bwd_args* a, gava_stream_t stream);
 size_t gava_attention_backward_workspace_bytes(int batch, int heads, int n_q);
@@ -264,9 +267,14 @@ int gava_vision_forward_train(const gava_vision_model* m, const float* x, float*
  * R = B*T_in*(n+1), SR = G + 2*B*T_in:  e0 fp32 [R][D] (embedding before ln_pre);  x fp32 [layers+1][R][D] (block inputs,
  * last slot = final stream);  x1 fp32 [layers][R][D] (stream after the attention branch);  qkv h16 [layers][R][3D];
  * pre h16 [layers][R][F] (fc1 output before QuickGELU);  sidekv h16 [layers][SR][2D] (prompt-row keys/values).
- * Nothing is copied: the residual stream hops x[i] -> x1[i] -> x[i+1].  Every block runs in full. */
+ * Nothing is copied: the residual stream hops x[i] -> x1[i] -> x[i+1]. */
 typedef struct {
   float* e0; float* x; float* x1; void* qkv; void* pre; void* sidekv;
+  /* optional (all three or none): run the LAST block on the CLS rows only, as gava_vision_forward does, and keep its
+   * CLS-row activations here: last_q h16 [B*T_in][D] (scaled queries), last_x1 fp32 [B*T_in][D], last_pre h16
+   * [B*T_in][F].  The block's K/V then sit in columns D..3D of its qkv slot; x1 / pre of that block are unused and only
+   * the CLS rows of the final stream are written. */
+  void* last_q; float* last_x1; void* last_pre;
 } gava_vision_saved;
 int gava_vision_forward_keep(const gava_vision_model* m, const float* x, float* cls_x, float* summary,
                              const gava_vision_saved* saved, void* workspace, size_t workspace_bytes,

@@ -177,13 +177,20 @@ def test_attention_backward_vision_with_prompt_rows_matches_autograd(BT, T, head
     dqkv = torch.zeros(BT * n, 3 * D, dtype=torch.bfloat16, device="cuda")
     part = torch.empty(BT, G + T + 1, 2 * D, dtype=torch.float32, device="cuda")
     dside = part.view(-1, 2 * D)
-    hip.attention_backward(qd[:, :D], qd[:, D:2 * D], qd[:, 2 * D:], do.cuda(), dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
-                           batch=BT, heads=heads, n=n, prec=BF, q_scale=0.125,
+    q_arg, do_arg, dq_arg, qbr = qd[:, :D], do.cuda(), dqkv[:, :D], 0
+    if n_q == 1:
+        # the CLS-only last block: queries, dout and dq live in their own [BT][D] buffers (one row per frame)
+        q_arg = qd.view(BT, n, 3 * D)[:, 0, :D].contiguous()
+        do_arg = do.cuda().view(BT, n, D)[:, 0].contiguous()
+        dq_sep = torch.zeros(BT, D, dtype=torch.bfloat16, device="cuda")
+        dq_arg, qbr = dq_sep, 1
+    hip.attention_backward(q_arg, qd[:, D:2 * D], qd[:, 2 * D:], do_arg, dq_arg, dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                           batch=BT, heads=heads, n=n, prec=BF, q_scale=0.125, q_batch_rows=qbr,
                            side_k=sd_[:, :D], side_v=sd_[:, D:], dside_k=dside[:, :D], dside_v=dside[:, D:],
                            n_g=G, T=T, has_summary=True, n_q=n_q, act_prec=act)
     tol = 3 * 2 ** -8     # P and dS are rounded to bf16 between the two MFMA products (as P is in the forward kernel)
     ref_q = q32.grad.view(BT, n, D)[:, :nq]
-    got_q = dqkv[:, :D].float().cpu().view(BT, n, D)[:, :nq]
+    got_q = dq_sep.float().cpu().view(BT, 1, D) if n_q == 1 else dqkv[:, :D].float().cpu().view(BT, n, D)[:, :nq]
     assert (got_q - ref_q).abs().max() <= tol * ref_q.abs().max() + 1e-6
     for name, got, ref in (("dk", dqkv[:, D:2 * D].float().cpu(), k32.grad), ("dv", dqkv[:, 2 * D:].float().cpu(), v32.grad)):
         assert (got - ref).abs().max() <= tol * ref.abs().max() + 1e-6, name
