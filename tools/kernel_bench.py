@@ -33,6 +33,10 @@ elif a.which == "fc2":
 elif a.which == "fc2nores":
     A, W, b, O = rn(R, F), rn(D, F, scale=F ** -0.5), rn(D, dtype=torch.float32), rn(R, D, dtype=torch.float32)
     fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32, prec=prec); fl = 2.0 * R * F * D
+elif a.which == "dhid":     # backward: dHID = dX . W2, QuickGELU' fused (pre-activations as aux)
+    A, W, O = rn(R, D), rn(F, D, scale=D ** -0.5), torch.empty(R, F, dtype=dt, device=d)
+    PRE = rn(R, F)
+    fn = lambda: hip.gemm(A, W, None, O, epilogue=hip.EPI_H16_QGELU_BWD, prec=prec, aux=PRE); fl = 2.0 * R * F * D
 elif a.which == "qkv":
     A, W, b, O = rn(R, D), rn(3 * D, D, scale=D ** -0.5), rn(3 * D, dtype=torch.float32), torch.empty(R, 3 * D, dtype=dt, device=d)
     fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_H16, prec=prec, scale_cols=D, scale=0.125); fl = 2.0 * R * 3 * D * D
