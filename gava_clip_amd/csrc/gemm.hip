@@ -436,7 +436,7 @@ void gemm256_kernel(const GemmParams p) {
   }
   set_src(m0, n0);
   stage(0, 0);
-  bool counted = false;   // the next wait may leave this wave's NSTORE epilogue stores in flight
+  int counted = 0;   // the next wait may leave this wave's NSTORE (1) or 2*NSTORE (2: pre-activation copy) epilogue stores in flight
   // diagnostic stamps (gava_debug_set_buffer; tools/gemm_stamps.py): cycles in the vmcnt wait, the barrier,
   // the stage body and the epilogue
   const bool stamp = p.dbg != nullptr;
@@ -451,9 +451,10 @@ void gemm256_kernel(const GemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
       const int g = j * nk + kt;
       if (stamp) { const unsigned long long t = clock64(); if (in_epi) tE += t - ts; else tC += t - ts; ts = t; in_epi = false; }
-      if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+      if (counted == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+      else if (counted == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NSTORE <= 63 ? 2 * NSTORE : 0) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      counted = false;
+      counted = 0;
       if (stamp) { const unsigned long long t = clock64(); tW += t - ts; ts = t; }
       __builtin_amdgcn_s_barrier();
       if (stamp) { const unsigned long long t = clock64(); tB += t - ts; ts = t; }
@@ -619,7 +620,7 @@ void gemm256_kernel(const GemmParams p) {
     // a full tile issued exactly NSTORE stores per wave after the in-flight stage: they may stay in flight
     // over the next wait (ragged tiles store fewer, and the accumulator-residual loads add to the count:
     // those cases fall back to vmcnt(0)).
-    counted = full && !ACC_RES && !(p.ablate & 4) && !(EPI == GAVA_EPI_H16_QGELU && p.aux_out);
+    counted = (full && !ACC_RES && !(p.ablate & 4)) ? ((EPI == GAVA_EPI_H16_QGELU && p.aux_out) ? 2 : 1) : 0;
     m0 = m0n; n0 = n0n;
   }
   if (stamp && lane == 0) {
