@@ -223,6 +223,23 @@ __global__ __launch_bounds__(64) void logits_mfma_kernel(const float* vn, const 
   }
 }
 
+// m[c] = mean_k normalise(t[c][k]): the class mean of the unit prompt features.  By linearity
+// mean_k <v, normalise(t_ck)> = <v, m_c>, so the logits need one GEMM against m (VitaCLIP_model.py:288-289).
+__global__ void class_mean_kernel(const float* t, float* m, int C, int n_kv, int E) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  for (int e = lane; e < E; e += 64) m[(long)c * E + e] = 0.f;
+  for (int k = 0; k < n_kv; ++k) {
+    const float* r = t + ((long)c * n_kv + k) * E;
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s += r[e] * r[e];
+    const float inv = 1.0f / sqrtf(wave_sum(s));
+    for (int e = lane; e < E; e += 64) m[(long)c * E + e] += r[e] * inv;
+  }
+  for (int e = lane; e < E; e += 64) m[(long)c * E + e] /= (float)n_kv;
+}
+
 // text_features[c] = normalise(mean_k tn[c][k])
 __global__ void text_feature_kernel(const float* tn, float* tf, int C, int n_kv, int E) {
   const int lane = threadIdx.x & 63;
@@ -279,19 +296,17 @@ extern "C" int gava_convert_h16(const float* in, void* out, size_t n, int prec, 
 extern "C" int gava_similarity_head(const float* video, const float* text, const float* logit_scale,
                                     const float* logit_bias, int B, int C, int n_kv, int E, float* logits,
                                     float* text_features, float* video_norm, gava_stream_t stream) {
-  // video_norm doubles as scratch for the normalised video rows; text rows are normalised into
-  // text_features' tail when n_kv == 1, otherwise the caller must pass n_kv == 1 (the only
-  // configuration reachable without the KAPT data files).
+  // video_norm receives the normalised video rows; text_features first holds the class means of the unit prompt
+  // features (the GEMM's second operand), then is re-normalised in place (VitaCLIP_model.py:290-291; with n_kv == 1
+  // that re-normalises an already unit row exactly as upstream does).
   if (!video || !text || !logit_scale || !logits || !text_features || !video_norm) return GAVA_EINVAL;
-  if (B <= 0 || C <= 0 || E <= 0 || n_kv != 1) return GAVA_EINVAL;
+  if (B <= 0 || C <= 0 || E <= 0 || n_kv <= 0 || E % 4) return GAVA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(l2norm_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, s, video, video_norm, B, E);
-  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((C + 3) / 4), dim3(256), 0, s, text, text_features, C, E);
-  if (E % 4) return GAVA_EINVAL;
+  if (n_kv == 1) hipLaunchKernelGGL(l2norm_rows_kernel, dim3((C + 3) / 4), dim3(256), 0, s, text, text_features, C, E);
+  else hipLaunchKernelGGL(class_mean_kernel, dim3((C + 3) / 4), dim3(256), 0, s, text, text_features, C, n_kv, E);
   hipLaunchKernelGGL(logits_mfma_kernel, dim3(((B + 15) / 16) * ((C + 15) / 16)), dim3(64), 0, s, video_norm,
                      text_features, logit_scale, logit_bias, B, C, E, logits);
-  // second normalisation of the per-class mean (VitaCLIP_model.py:290-291); with n_kv == 1 the
-  // mean is the row itself, so this re-normalises an already unit row exactly as upstream does.
   hipLaunchKernelGGL(text_feature_kernel, dim3((C + 3) / 4), dim3(256), 0, s, text_features, text_features, C, 1, E);
   GAVA_CHECK_LAUNCH();
   return GAVA_OK;

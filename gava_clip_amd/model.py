@@ -738,28 +738,24 @@ class VitaCLIP(nn.Module):
         else:
             Bg, Cn = video.shape[0], text.shape[0]
             n_kv = self.prompt_learner.n_kv if self.use_text_prompt_learning else 1
-            logits = torch.empty(Bg, Cn, dtype=torch.float32, device=x.device)
-            tfeat = torch.empty(Cn, sh["E"], dtype=torch.float32, device=x.device)
+            if desc_wise and self.use_text_prompt_learning:
+                n_cls, n_kv = Cn, 1      # per-description logits (VitaCLIP_model.py:265-276): every prompt is its own "class"
+            else:
+                n_cls = Cn // n_kv
+            logits = torch.empty(Bg, n_cls, dtype=torch.float32, device=x.device)
+            tfeat = torch.empty(n_cls, sh["E"], dtype=torch.float32, device=x.device)
             vnorm = torch.empty(Bg, sh["E"], dtype=torch.float32, device=x.device)
             ls = self.logit_scale.detach().float().reshape(1)
-            lb = self.logit_bias.detach().float().reshape(1) if (self.logit_bias is not None and n_kv == 1) else None
-            hip.check(lib.gava_similarity_head(hip.ptr(video), hip.ptr(text), hip.ptr(ls), hip.ptr(lb), Bg, Cn, 1,
+            lb = self.logit_bias.detach().float().reshape(1) if self.logit_bias is not None else None
+            hip.check(lib.gava_similarity_head(hip.ptr(video), hip.ptr(text), hip.ptr(ls), hip.ptr(lb), Bg, n_cls, n_kv,
                                                sh["E"], hip.ptr(logits), hip.ptr(tfeat), hip.ptr(vnorm), hip.stream_ptr()),
                       "gava_similarity_head")
             self.last.update(video_features=vnorm, summary=summary)
-            per_prompt = logits
-            if n_kv > 1:
-                # knowledge-aware prompts: n_kv prompts per class, class logit = mean over them, class feature = the
-                # re-normalised mean of the unit prompt features (VitaCLIP_model.py:288-291); (B, C*n_kv) -> (B, C) glue
-                logits = per_prompt.view(Bg, Cn // n_kv, n_kv).mean(-1)
-                if self.logit_bias is not None:
-                    logits = logits + self.logit_bias.detach()
-                tfeat = tfeat.view(Cn // n_kv, n_kv, sh["E"]).mean(1)
-                tfeat = tfeat / tfeat.norm(dim=-1, keepdim=True)
             if self.use_text_prompt_learning:
                 self.text_features = tfeat            # VitaCLIP_model.py:293
             if desc_wise and self.use_text_prompt_learning:
-                logits = [per_prompt[:, i:i + n_kv] for i in range(0, Cn, n_kv)]   # list of (B, n_kv), :265-276
+                k = self.prompt_learner.n_kv
+                logits = [logits[:, i:i + k] for i in range(0, Cn, k)]   # list of (B, n_kv)
 
         # auxiliary heads: inactive at every accelerated configuration; kept as PyTorch glue on the device so that
         # callers passing video_nte / memory still get the reference's outputs - and, in training, its gradients

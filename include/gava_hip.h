@@ -191,8 +191,10 @@ int gava_text_forward(const gava_text_model* m, const int32_t* tokens, const flo
 
 /* Similarity head (VitaCLIP_model.py:255,287-293): L2-normalise video [B][E] and text
  * [C*n_kv][E] rows (no epsilon), logits[b][c] = exp(logit_scale) * mean_k <v_b, t_{c,k}>
- * (+ logit_bias if not NULL); text_features[c] = normalise(mean_k t_{c,k}).  All fp32.
- * video_norm (optional) receives the normalised video features. */
+ * (+ logit_bias if not NULL), computed as one exact-fp32 GEMM against the class means of the unit
+ * prompt features (the mean commutes with the dot product); text_features[c] = normalise(mean_k
+ * t_{c,k}) [C][E].  n_kv = prompts per class (1 for plain prompts, the number of knowledge versions
+ * for KAPT).  All fp32.  video_norm receives the normalised video features. */
 int gava_similarity_head(const float* video, const float* text, const float* logit_scale,
                          const float* logit_bias, int B, int C, int n_kv, int E, float* logits,
                          float* text_features, float* video_norm, gava_stream_t stream);

@@ -185,6 +185,24 @@ def test_similarity_head():
     assert torch.allclose(logits, ls.exp() * vr @ tr.t(), rtol=1e-5, atol=1e-5)
 
 
+def test_similarity_head_with_several_prompts_per_class():
+    """n_kv prompts per class (knowledge-aware prompts): class logit = mean over its prompts of the cosine logits, class
+    feature = re-normalised mean of the unit prompt features (VitaCLIP_model.py:282-291), plus the logit bias."""
+    d = dev()
+    lib = hip.load()
+    B, C_, K, E = 7, 3, 5, 512
+    v, t = rnd((B, E), 2.0, 41).to(d), rnd((C_ * K, E), 3.0, 42).to(d)
+    ls, lb = torch.tensor([math.log(1 / 0.07)], device=d), torch.tensor([-0.5], device=d)
+    logits, tf, vn = torch.zeros(B, C_, device=d), torch.zeros(C_, E, device=d), torch.zeros(B, E, device=d)
+    hip.check(lib.gava_similarity_head(hip.ptr(v), hip.ptr(t), hip.ptr(ls), hip.ptr(lb), B, C_, K, E, hip.ptr(logits),
+                                       hip.ptr(tf), hip.ptr(vn), hip.stream_ptr()), "head")
+    vr, tr = v / v.norm(dim=-1, keepdim=True), t / t.norm(dim=-1, keepdim=True)
+    want = (ls.exp() * vr @ tr.t()).view(B, C_, K).mean(-1) + lb
+    m = tr.view(C_, K, E).mean(1)
+    assert torch.allclose(logits, want, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(tf, m / m.norm(dim=-1, keepdim=True), rtol=1e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("prec,tol", [(hip.PREC_F16, 2e-5), (hip.PREC_BF16, 2e-4)])
 def test_split_precision_chain(prec, tol):
     """LN(split) -> GEMM(QGELU, split out) -> GEMM with [W_hi|W_hi|W_lo] weights tracks the fp32 chain
