@@ -1,5 +1,6 @@
-// attention_bwd.hip — MFMA backward of the vision-block attention (softmax(Q K^T) V over the frame's rows + the
-// gathered prompt rows), built from the same pieces as attention.hip:
+// attention_bwd.hip — MFMA backward of softmax(Q K^T) V, head dim 64: the vision-block attention (the frame's rows +
+// the gathered prompt rows), the T-token summary attention and the causal text attention, built from the same pieces as
+// attention.hip:
 //   S^T = K Q^T accumulators ARE the B operand of the next product, transposed operands come from the
 //   hardware-transposing LDS read, 160-byte padded LDS rows, one workgroup (4 waves) per (frame, head).
 // Two kernels (the two contraction directions need the score tile in the two orientations):
@@ -45,7 +46,7 @@ static __device__ __forceinline__ long side_row_of(const gava::AttnBwdMfmaParams
                             : (long)p.n_g + p.batch + frame;
 }
 
-template <class P, class PA, int NKT>
+template <class P, class PA, int NKT, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const gava::AttnBwdMfmaParams p) {
   constexpr int KP = NKT * 16;
   constexpr int NIT = (KP * 8 + 255) / 256;
@@ -140,9 +141,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const gava::AttnBwd
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      if (kt * 16 + 16 > p.n_keys) {
+      if (kt * 16 + 16 > p.n_keys || (CAUSAL && kt * 16 + 15 > qt * 16)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[kt][r] = (kt * 16 + 4 * fg + r < p.n_keys) ? s[kt][r] : -INFINITY;
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * fg + r;
+          s[kt][r] = (key < p.n_keys && (!CAUSAL || key <= qi)) ? s[kt][r] : -INFINITY;
+        }
       }
       mx = fmaxf(fmaxf(mx, s[kt][0]), fmaxf(s[kt][1], fmaxf(s[kt][2], s[kt][3])));
     }
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const gava::AttnBwd
   }
 }
 
-template <class P, class PA, int NQT>
+template <class P, class PA, int NQT, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const gava::AttnBwdMfmaParams p) {
   static_assert(NQT % 2 == 0, "query tiles are consumed in pairs (32-deep MFMA contraction)");
   constexpr int QP = NQT * 16;
@@ -323,7 +327,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const gava::AttnBw
         const float l2a[4] = {l2.x, l2.y, l2.z, l2.w}, dla[4] = {dl.x, dl.y, dl.z, dl.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pr = key_ok ? __builtin_amdgcn_exp2f(fmaf(st[t][r], LOG2E, -l2a[r])) : 0.f;
+          const bool vis = key_ok && (!CAUSAL || key <= (2 * c + t) * 16 + 4 * fg + r);
+          const float pr = vis ? __builtin_amdgcn_exp2f(fmaf(st[t][r], LOG2E, -l2a[r])) : 0.f;
           pv[4 * t + r] = pr;
           dsv[4 * t + r] = pr * (pt[t][r] - dla[r]);
         }
@@ -363,19 +368,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const gava::AttnBw
   }
 }
 
-template <class P, class PA>
+template <class P, class PA, bool CAUSAL>
 int launch(const gava::AttnBwdMfmaParams& p, hipStream_t s) {
   dim3 grid(p.batch * p.heads), block(256);
   const int kt = (p.n_keys + 15) / 16, qt2 = ((p.n_q + 15) / 16 + 1) / 2 * 2;
-  if (kt <= 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, PA, 2>), grid, block, 0, s, p);
-  else if (kt <= 6) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, PA, 6>), grid, block, 0, s, p);
-  else if (kt <= 14) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, PA, 14>), grid, block, 0, s, p);
-  else if (kt <= 20) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, PA, 20>), grid, block, 0, s, p);
+  if (kt <= 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, PA, 2, CAUSAL>), grid, block, 0, s, p);
+  else if (kt <= 6) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, PA, 6, CAUSAL>), grid, block, 0, s, p);
+  else if (kt <= 14) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, PA, 14, CAUSAL>), grid, block, 0, s, p);
+  else if (kt <= 20) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, PA, 20, CAUSAL>), grid, block, 0, s, p);
   else return GAVA_EINVAL;
-  if (qt2 <= 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, PA, 2>), grid, block, 0, s, p);
-  else if (qt2 <= 6) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, PA, 6>), grid, block, 0, s, p);
-  else if (qt2 <= 14) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, PA, 14>), grid, block, 0, s, p);
-  else if (qt2 <= 18) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, PA, 18>), grid, block, 0, s, p);
+  if (qt2 <= 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, PA, 2, CAUSAL>), grid, block, 0, s, p);
+  else if (qt2 <= 6) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, PA, 6, CAUSAL>), grid, block, 0, s, p);
+  else if (qt2 <= 14) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, PA, 14, CAUSAL>), grid, block, 0, s, p);
+  else if (qt2 <= 18) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, PA, 18, CAUSAL>), grid, block, 0, s, p);
   else return GAVA_EINVAL;
   GAVA_CHECK_LAUNCH();
   return GAVA_OK;
@@ -384,10 +389,16 @@ int launch(const gava::AttnBwdMfmaParams& p, hipStream_t s) {
 }  // namespace
 
 namespace gava {
-int attention_bwd_mfma(const AttnBwdMfmaParams& p, int prec, int act_prec, hipStream_t s) {
-  if (prec == GAVA_PREC_F16 && act_prec == GAVA_PREC_F16) return launch<PrecF16, PrecF16>(p, s);
-  if (prec == GAVA_PREC_BF16 && act_prec == GAVA_PREC_BF16) return launch<PrecBF16, PrecBF16>(p, s);
-  if (prec == GAVA_PREC_BF16 && act_prec == GAVA_PREC_F16) return launch<PrecBF16, PrecF16>(p, s);   // fp16 forward, bf16 gradients
+int attention_bwd_mfma(const AttnBwdMfmaParams& p, int prec, int act_prec, int causal, hipStream_t s) {
+  if (causal) {   // the text tower (77 tokens, no prompt rows): same-precision only
+    if (p.n_keys != p.n_kmain || prec != act_prec) return GAVA_EINVAL;
+    if (prec == GAVA_PREC_F16) return launch<PrecF16, PrecF16, true>(p, s);
+    if (prec == GAVA_PREC_BF16) return launch<PrecBF16, PrecBF16, true>(p, s);
+    return GAVA_EINVAL;
+  }
+  if (prec == GAVA_PREC_F16 && act_prec == GAVA_PREC_F16) return launch<PrecF16, PrecF16, false>(p, s);
+  if (prec == GAVA_PREC_BF16 && act_prec == GAVA_PREC_BF16) return launch<PrecBF16, PrecBF16, false>(p, s);
+  if (prec == GAVA_PREC_BF16 && act_prec == GAVA_PREC_F16) return launch<PrecBF16, PrecF16, false>(p, s);   // fp16 forward, bf16 gradients
   return GAVA_EINVAL;
 }
 }  // namespace gava

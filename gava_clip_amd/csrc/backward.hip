@@ -2,7 +2,8 @@
 // loss.backward() through VitaCLIP.forward; every transformer weight is frozen, VitaCLIP_model.py:230-239, so the
 // path needs dgrad only: gradients flow THROUGH the frozen GEMMs to the prompt parameters).
 //   * dgrad GEMMs are gava_gemm on transposed weight copies (dX = dY . W  ==  gemm(A = dY, W = W^T [in][out])).
-//   * this file: LayerNorm backward, QuickGELU backward, softmax-attention backward.
+//   * this file: LayerNorm backward, QuickGELU backward and the entry point of the attention backward (kernels in
+//     attention_bwd.hip).
 // Gradient operands are bf16 (fp32 range: no loss scaling needed inside the library), accumulation fp32.
 #include "common.h"
 #include "internal.h"
@@ -108,92 +109,6 @@ __global__ __launch_bounds__(256) void qgelu_bwd_kernel(const unsigned short* pr
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Attention backward, short sequences (n <= 88 keys; the text tower's 77).  One workgroup per (sequence, head):
-//   S = Q K^T (Q already carries 1/sqrt(dh)), P = softmax(S + mask), O = P V
-//   dV = P^T dO;  dP = dO V^T;  dS = P * (dP - rowsum(P * dP));  dQ = q_scale * dS K;  dK = dS^T Q
-// Everything fp32 in LDS/registers: 5 products of n x n x 64 are ~2 MFLOP per head, not worth MFMA tiles;
-// the vision-side (n = 214, 6144 heads per layer) version is MFMA work of its own.
-constexpr int ATT_BWD_MAXN = 88, DH = 64;   // 154 KiB of LDS at n = 88
-
-struct AttnBwdParams {
-  const unsigned short* q; const unsigned short* k; const unsigned short* v; long ld_qkv;
-  const unsigned short* dout; long ld_dout;
-  unsigned short* dq; unsigned short* dk; unsigned short* dv; long ld_dqkv;
-  int heads, n, causal;
-  float q_scale;
-};
-
-template <class P>
-__global__ __launch_bounds__(256) void attention_bwd_small_kernel(const AttnBwdParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int n = p.n, tid = threadIdx.x;
-  const int b = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
-  float* Q = reinterpret_cast<float*>(smem_raw);         // [n][DH+1] each (padded: conflict-free column walks)
-  constexpr int LDT = DH + 1;
-  float* K = Q + n * LDT;
-  float* V = K + n * LDT;
-  float* dO = V + n * LDT;
-  float* Pm = dO + n * LDT;                               // [n][n+1]  P, then dS
-  float* dP = Pm + n * (n + 1);                           // [n][n+1]
-  const int LDP = n + 1;
-  const long row0 = (long)b * n;
-  for (int e = tid; e < n * DH; e += 256) {
-    const int i = e / DH, d = e % DH;
-    const long r = row0 + i;
-    Q[i * LDT + d] = P::up(p.q[r * p.ld_qkv + h * DH + d]);
-    K[i * LDT + d] = P::up(p.k[r * p.ld_qkv + h * DH + d]);
-    V[i * LDT + d] = P::up(p.v[r * p.ld_qkv + h * DH + d]);
-    dO[i * LDT + d] = P::up(p.dout[r * p.ld_dout + h * DH + d]);
-  }
-  __syncthreads();
-  // S and dP
-  for (int e = tid; e < n * n; e += 256) {
-    const int i = e / n, j = e % n;
-    float s = 0.f, t = 0.f;
-    if (!p.causal || j <= i) {
-#pragma unroll 16
-      for (int d = 0; d < DH; ++d) { s += Q[i * LDT + d] * K[j * LDT + d]; t += dO[i * LDT + d] * V[j * LDT + d]; }
-    } else {
-      s = -INFINITY;
-    }
-    Pm[i * LDP + j] = s; dP[i * LDP + j] = t;
-  }
-  __syncthreads();
-  // row softmax and dS, one wave per row
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int i = wave; i < n; i += 4) {
-    float m = -INFINITY;
-    for (int j = lane; j < n; j += 64) m = fmaxf(m, Pm[i * LDP + j]);
-#pragma unroll
-    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    float sum = 0.f;
-    for (int j = lane; j < n; j += 64) { const float e = __expf(Pm[i * LDP + j] - m); Pm[i * LDP + j] = e; sum += e; }
-    sum = wave_sum(sum);
-    const float r = 1.f / sum;
-    float delta = 0.f;
-    for (int j = lane; j < n; j += 64) { const float pj = Pm[i * LDP + j] * r; Pm[i * LDP + j] = pj; delta += pj * dP[i * LDP + j]; }
-    delta = wave_sum(delta);
-    // dP row becomes dS; the P row is kept for dV
-    for (int j = lane; j < n; j += 64) dP[i * LDP + j] = Pm[i * LDP + j] * (dP[i * LDP + j] - delta);
-  }
-  __syncthreads();
-  // dQ[i][d] = q_scale * sum_j dS[i][j] K[j][d];  dK[j][d] = sum_i dS[i][j] Q[i][d];  dV[j][d] = sum_i P[i][j] dO[i][d]
-  for (int e = tid; e < n * DH; e += 256) {
-    const int i = e / DH, d = e % DH;
-    float aq = 0.f, ak = 0.f, av = 0.f;
-    for (int j = 0; j < n; ++j) {
-      aq += dP[i * LDP + j] * K[j * LDT + d];
-      ak += dP[j * LDP + i] * Q[j * LDT + d];
-      av += Pm[j * LDP + i] * dO[j * LDT + d];
-    }
-    const long r = row0 + i;
-    p.dq[r * p.ld_dqkv + h * DH + d] = P::cvt(aq * p.q_scale);
-    p.dk[r * p.ld_dqkv + h * DH + d] = P::cvt(ak);
-    p.dv[r * p.ld_dqkv + h * DH + d] = P::cvt(av);
-  }
-}
-
 }  // namespace
 
 extern "C" int gava_layernorm_backward(const gava_layernorm_bwd_args* a, gava_stream_t stream) {
@@ -232,26 +147,9 @@ extern "C" int gava_attention_backward(const gava_attention_bwd_args* a, gava_st
   if (a->prec != GAVA_PREC_F16 && a->prec != GAVA_PREC_BF16) return GAVA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int n_side = a->side_k ? a->n_g + a->T + (a->has_summary ? 1 : 0) : 0;
-  if (n_side == 0 && a->n_q == 0 && a->n <= ATT_BWD_MAXN) {
-    AttnBwdParams p{(const unsigned short*)a->q, (const unsigned short*)a->k, (const unsigned short*)a->v, a->ld_qkv,
-                    (const unsigned short*)a->dout, a->ld_dout, (unsigned short*)a->dq, (unsigned short*)a->dk,
-                    (unsigned short*)a->dv, a->ld_dqkv, a->heads, a->n, a->causal, a->q_scale};
-    const size_t lds = (size_t)(4 * a->n * (DH + 1) + 2 * a->n * (a->n + 1)) * sizeof(float);
-    if (lds > 160 * 1024) return GAVA_EINVAL;
-    dim3 grid(a->batch * a->heads), block(256);
-    if (a->prec == GAVA_PREC_F16) {
-      if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)attention_bwd_small_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GAVA_ELAUNCH;
-      hipLaunchKernelGGL(attention_bwd_small_kernel<PrecF16>, grid, block, lds, s, p);
-    } else {
-      if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)attention_bwd_small_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GAVA_ELAUNCH;
-      hipLaunchKernelGGL(attention_bwd_small_kernel<PrecBF16>, grid, block, lds, s, p);
-    }
-    GAVA_CHECK_LAUNCH();
-    return GAVA_OK;
-  }
-  // vision blocks: n main rows per frame, the first n_q of them query (0 = all), prompt rows gathered as in
-  // gava_attention: MFMA kernels (attention_bwd.hip)
-  if (a->causal || !a->workspace) return GAVA_EINVAL;
+  // n main rows per sequence / frame, the first n_q of them query (0 = all), prompt rows (vision blocks) gathered as in
+  // gava_attention; causal only without prompt rows (text tower): MFMA kernels (attention_bwd.hip)
+  if (!a->workspace || (a->causal && (n_side || a->n_q))) return GAVA_EINVAL;
   if (n_side && (!a->side_v || !a->dside_k || !a->dside_v || a->n_g < 0 || a->T <= 0 || a->batch % a->T)) return GAVA_EINVAL;
   if ((a->ld_qkv | a->ld_side | a->ld_dout) % 8) return GAVA_EINVAL;
   if ((((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->dout | (uintptr_t)a->side_k | (uintptr_t)a->side_v |
@@ -274,7 +172,7 @@ extern "C" int gava_attention_backward(const gava_attention_bwd_args* a, gava_st
   p.q_pad = ((p.n_q + 15) / 16 + 1) / 2 * 32;
   p.q_scale = a->q_scale;
   if (p.n_keys > 320 || p.n_q > a->n || p.n_q > 288) return GAVA_EINVAL;
-  return gava::attention_bwd_mfma(p, a->prec, a->act_prec_set ? a->act_prec : a->prec, s);
+  return gava::attention_bwd_mfma(p, a->prec, a->act_prec_set ? a->act_prec : a->prec, a->causal, s);
 }
 
 extern "C" size_t gava_attention_backward_workspace_bytes(int batch, int heads, int n_q) {

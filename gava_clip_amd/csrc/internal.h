@@ -24,7 +24,7 @@ struct AttnBwdMfmaParams {
   int batch, heads, n_q, n_kmain, n_g, T, has_summary, n_keys, q_pad;
   float q_scale;
 };
-int attention_bwd_mfma(const AttnBwdMfmaParams& p, int prec, int act_prec, hipStream_t s);
+int attention_bwd_mfma(const AttnBwdMfmaParams& p, int prec, int act_prec, int causal, hipStream_t s);
 // CUs the persistent GEMM leaves free on its next launches (so a concurrent stream can run small kernels)
 void set_gemm_cu_reserve(int n);
 int gemm_cu_reserve();   // set by gava_debug_set_buffer; nullptr = stamps off

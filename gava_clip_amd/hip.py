@@ -296,9 +296,7 @@ def attention_backward(q, k, v, dout, dq, dk, dv, *, batch, heads, n, prec, caus
     a.dside_k, a.dside_v = ptr(dside_k), ptr(dside_v)
     a.ld_dside = dside_k.stride(0) if dside_k is not None else 0
     a.n_g, a.T, a.has_summary, a.n_q = n_g, T, int(has_summary), n_q
-    ws = None
-    if side_k is not None or n > 88:
-        ws = torch.empty(load().gava_attention_backward_workspace_bytes(batch, heads, n_q or n), dtype=torch.uint8, device=q.device)
+    ws = torch.empty(load().gava_attention_backward_workspace_bytes(batch, heads, n_q or n), dtype=torch.uint8, device=q.device)
     a.workspace = ptr(ws)
     a.q, a.k, a.v, a.ld_qkv = ptr(q), ptr(k), ptr(v), k.stride(0)
     a.dout, a.ld_dout = ptr(dout), dout.stride(0)

@@ -223,17 +223,19 @@ int gava_layernorm_backward(const gava_layernorm_bwd_args* a, gava_stream_t stre
 /* QuickGELU backward: dpre = dh * s*(1 + 1.702*pre*(1-s)), s = sigmoid(1.702*pre); h16 in/out, n % 4 == 0. */
 int gava_qgelu_backward(const void* pre, const void* dh, void* dpre, size_t n, int prec, gava_stream_t stream);
 
-/* Softmax-attention backward.  q (already scaled by 1/sqrt(dh)), k, v, dout: h16 rows [batch*n][ld], head h at columns
- * [64h, 64h+64); writes dq (times q_scale, the factor folded into q), dk, dv as h16 rows [batch*n][ld_dqkv].
- *   - short sequences (side_k == NULL, n <= 88: the text tower, nn.MultiheadAttention at text_encoder.py:71,83, and
- *     the T-token summary attention, vision_encoder_utils.py:169-170), optionally causal;
+/* Softmax-attention backward (MFMA kernels).  q (already scaled by 1/sqrt(dh)), k, v, dout: h16 rows [batch*n][ld],
+ * head h at columns [64h, 64h+64); writes dq (times q_scale, the factor folded into q), dk, dv as h16 rows
+ * [batch*n][ld_dqkv].  n (+ prompt rows) <= 320.
+ *   - plain or causal sequences without prompt rows (side_k == NULL): the text tower (nn.MultiheadAttention at
+ *     text_encoder.py:71,83) and the T-token summary attention (vision_encoder_utils.py:169-170);
  *   - vision blocks (vision_encoder_utils.py:190-191): keys = the n rows of the frame + the gathered prompt rows
  *     [n_g global | T local rows of the clip | the frame's summary row] of side_k/side_v (same layout as
- *     gava_attention); n + prompts <= 256.  Prompt rows are shared between frames, so their gradients come out as
+ *     gava_attention).  Prompt rows are shared between frames, so their gradients come out as
  *     per-frame partials dside_k / dside_v fp32 [batch][n_g + T + 1][ld_dside] (plain stores; row order global,
  *     local, summary) which the caller sums over the frames sharing a row.  n_q != 0: only the first n_q rows of
- *     each frame are queries.  `workspace`: gava_attention_backward_workspace_bytes(batch, heads, n_q) bytes of
- *     scratch (per-query softmax statistics handed from the dQ kernel to the dK/dV kernel). */
+ *     each frame are queries.
+ * `workspace`: gava_attention_backward_workspace_bytes(batch, heads, n_q) bytes of scratch (per-query softmax
+ * statistics handed from the dQ kernel to the dK/dV kernel). */
 typedef struct {
   const void* q; const void* k; const void* v; int64_t ld_qkv;
   const void* dout; int64_t ld_dout;
