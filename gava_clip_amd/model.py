@@ -401,6 +401,8 @@ class VitaCLIP(nn.Module):
         # independent; opt-in because a benchmark must not skip work.  Invalidated by any parameter update.
         self.cache_text_features = False
         self.text_on_side_stream = os.environ.get("GAVA_TEXT_STREAM", "1") != "0"
+        self.trim_text_rows = os.environ.get("GAVA_TEXT_TRIM", "1") != "0"   # skip the rows behind the last EOT (see _pack)
+        self.text_rows_per_prompt = text_context_length
         # training: keep the backward's activations (~21 GB at B = 64, T = 8) instead of recomputing them per block, as
         # long as they fit this budget; beyond it the backward recomputes from the block inputs only
         self.keep_activation_bytes = int(float(os.environ.get("GAVA_KEEP_ACT_GB", "96")) * 2 ** 30)
@@ -436,7 +438,7 @@ class VitaCLIP(nn.Module):
             if p.dim() >= 2 and not p.requires_grad and not any(k in name for k in self._PASS_THROUGH):
                 ver += p._version
         ps = next(self.parameters())
-        return (self.prec, self.text_split_precision, ps.device, addr, ver)
+        return (self.prec, self.text_split_precision, self.trim_text_rows, ps.device, addr, ver)
 
     def _summary_weight_versions(self):
         """Versions of the only TRAINABLE weights that have 16-bit copies (summary_attn_layer projections): an optimizer
@@ -541,8 +543,15 @@ class VitaCLIP(nn.Module):
             tok0 = torch.cat(self.tokenized_prompts).to(device=dev)
             eot_col = (tok0 == t.vocab_size - 1).nonzero()[:, -1]
             assert eot_col.numel() == tok0.shape[0], "every prompt must contain exactly one EOT token"
-            eot = (torch.arange(tok0.shape[0], device=dev) * sh["L"] + eot_col).to(torch.int32).contiguous()
-            tok = self.prompt_learner.embedding_token_ids().to(device=dev, dtype=torch.int32).contiguous()
+            # Causal attention: the EOT row - the only one the text features read (text_encoder.py:169) - depends on the
+            # rows up to itself only, and LayerNorm / MLP are row-wise.  Rows behind the last EOT of any prompt are
+            # dead work (the reference pads every prompt to 77): the tower runs on the first L_eff positions, results
+            # identical.  ("X X .. name." prompts: ~15-20 of 77.)
+            L_eff = min(sh["L"], max(int(eot_col.max()) + 1, 1 + sh["n_ctx"]))
+            self.text_rows_per_prompt = L_eff if self.trim_text_rows else sh["L"]
+            L_eff = self.text_rows_per_prompt
+            eot = (torch.arange(tok0.shape[0], device=dev) * L_eff + eot_col).to(torch.int32).contiguous()
+            tok = self.prompt_learner.embedding_token_ids()[:, :L_eff].to(device=dev, dtype=torch.int32).contiguous()
             packed.update(txt=dict(token_embedding=K(self._f32(t.token_embedding.weight)),
                                    positional_embedding=K(self._f32(t.positional_embedding)),
                                    lnf_g=K(self._f32(t.ln_final.weight)), lnf_b=K(self._f32(t.ln_final.bias)),
@@ -611,7 +620,7 @@ class VitaCLIP(nn.Module):
         tok = pk["tokens"]
         n = tok.shape[0]
         m = hip.TextModel()
-        m.n_prompts, m.L, m.W, m.H, m.layers = n, sh["L"], sh["W"], sh["TH"], sh["TL"]
+        m.n_prompts, m.L, m.W, m.H, m.layers = n, self.text_rows_per_prompt, sh["W"], sh["TH"], sh["TL"]
         m.E, m.n_ctx, m.prec = sh["E"], sh["n_ctx"], self.prec
         m.split = int(self.text_split_precision)
         for k, val in pk["txt"].items():

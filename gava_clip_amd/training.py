@@ -54,7 +54,7 @@ def text_forward_train(model, ctx_param):
     tok = pk["tokens"]
     n = tok.shape[0]
     m = hip.TextModel()
-    m.n_prompts, m.L, m.W, m.H, m.layers = n, sh["L"], sh["W"], sh["TH"], sh["TL"]
+    m.n_prompts, m.L, m.W, m.H, m.layers = n, model.text_rows_per_prompt, sh["W"], sh["TH"], sh["TL"]
     m.E, m.n_ctx, m.prec = sh["E"], sh["n_ctx"], model.prec
     m.split = int(model.text_split_precision)
     for k, val in pk["txt"].items():
@@ -66,7 +66,7 @@ def text_forward_train(model, ctx_param):
     ws = model._workspace("text", nbytes, tok.device)
     ctx = ctx_param.detach().float().contiguous()
     out = torch.empty(n, sh["E"], dtype=torch.float32, device=tok.device)
-    saved = torch.empty(sh["TL"] + 1, n * sh["L"], sh["W"], dtype=torch.float32, device=tok.device)
+    saved = torch.empty(sh["TL"] + 1, n * model.text_rows_per_prompt, sh["W"], dtype=torch.float32, device=tok.device)
     hip.check(lib.gava_text_forward_train(C.byref(m), hip.ptr(tok), hip.ptr(ctx), hip.ptr(pk["eot"]), hip.ptr(out),
                                           hip.ptr(saved), hip.ptr(ws), ws.numel(), hip.stream_ptr()),
               "gava_text_forward_train")
@@ -78,7 +78,7 @@ def text_backward(model, saved, dtext):
     sh = model._shape
     pk = model._pack()
     bw = model._pack_text_backward()
-    n, L, W, H, E, n_ctx = pk["tokens"].shape[0], sh["L"], sh["W"], sh["TH"], sh["E"], sh["n_ctx"]
+    n, L, W, H, E, n_ctx = pk["tokens"].shape[0], model.text_rows_per_prompt, sh["W"], sh["TH"], sh["E"], sh["n_ctx"]
     R = n * L
     dev = dtext.device
     bf = torch.bfloat16

@@ -200,3 +200,21 @@ def test_forward_is_hipgraph_capturable_and_side_streams_join():
         want = m(x)[0]
     assert torch.equal(got, want)
     assert not torch.equal(got, ref)
+
+
+def test_text_rows_behind_the_last_eot_are_dead_work():
+    """The text tower runs on the first L_eff = last EOT position + 1 rows of every prompt (causal attention: the EOT
+    row cannot see later rows); the reference pads all prompts to 77.  Same logits and text features as the full run."""
+    m, _ = build(TINY)
+    m.debug_taps = False
+    x = torch.from_numpy(synth.synth_clip(2, TINY.num_frames, TINY.input_size)).cuda()
+    with torch.no_grad():
+        a = m(x)[0].clone()
+        ta = m.text_features.clone()
+        assert m.text_rows_per_prompt < 30
+        m.trim_text_rows = False
+        b = m(x)[0].clone()
+        tb = m.text_features.clone()
+        assert m.text_rows_per_prompt == 77
+    assert (a - b).abs().max() <= 1e-6 * b.abs().max()
+    assert (ta - tb).abs().max() <= 1e-6
