@@ -30,6 +30,15 @@ struct SideStream {
 };
 SideStream g_side;
 
+// CUs the persistent QKV GEMM leaves to the prompt-path kernels on the side stream.  Measured (tools/side_probe.py): with
+// 8 or 16 CUs left out a 128-workgroup kernel on the second stream still waits for the GEMM's first workgroups to retire
+// (0.23 ms instead of 0.01 ms) - workgroups are dealt round-robin to the XCDs' shader engines and the dispatch blocks on
+// the first engine without a free CU; with 32 (one CU per engine) it runs at its stand-alone speed and the GEMM is 4 % slower.
+int side_cus() {
+  static const int n = getenv("GAVA_SIDE_CUS") ? atoi(getenv("GAVA_SIDE_CUS")) : 32;
+  return n;
+}
+
 struct Carver {
   char* base; size_t off, cap;
   Carver(void* b, size_t c) : base((char*)b), off(0), cap(c) {}
@@ -55,10 +64,20 @@ int ln(const float* in, long in_stride, const int32_t* idx, const float* g, cons
   return gava_layernorm(&a, s);
 }
 
+// LayerNorm folding (gava_gemm_args): producer outputs and/or consumer inputs of one GEMM call
+struct Fold {
+  void* x16 = nullptr; long ld_x16 = 0; float* rowsum = nullptr;                          // producer
+  const float* stats = nullptr; const float* s = nullptr; const float* t = nullptr;       // consumer
+};
+
 int gemm(const void* A, long lda, const void* W, long ldw, const float* bias, void* out, long ldo, int M, int N, int K,
          int epi, int prec, gava_stream_t s, const float* resid = nullptr, long ldr = 0, int scale_cols = 0,
-         float scale = 1.f, int split_out = 0, void* aux_out = nullptr) {
+         float scale = 1.f, int split_out = 0, void* aux_out = nullptr, const Fold* fold = nullptr) {
   gava_gemm_args a{};
+  if (fold) {
+    a.x16_out = fold->x16; a.ld_x16 = fold->ld_x16; a.rowsum_out = fold->rowsum;
+    a.fold_stats = fold->stats; a.fold_s = fold->s; a.fold_t = fold->t;
+  }
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo;
   a.resid = resid; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.prec = prec;
   a.scale_cols = scale_cols; a.scale = scale; a.split_out = split_out; a.aux_out = aux_out;
@@ -70,6 +89,7 @@ struct VisionWs {
   void* CLS16; float* CP; void* CPn; void* SQKV; void* SMIX; float* SUMM; void* SIDEn; void* SIDEKV;
   void* CLSPOST; float* PROJ;
   void* XNC; void* QC; void* MIXC; void* HIDC;   // last block: CLS rows only
+  float* RSUM; float* STATS;                     // LayerNorm folding: row-sum partials [R][D/64][2], (mean, rstd) [R up to 256][2]
   size_t total;
 };
 
@@ -99,6 +119,8 @@ VisionWs carve_vision(const gava_vision_model* m, void* ws, size_t cap) {
   w.QC = c.take(BT * D * 2);
   w.MIXC = c.take(BT * D * 2);
   w.HIDC = c.take(BT * F * 2);
+  w.RSUM = (float*)c.take(R * (D / 64) * 8);
+  w.STATS = (float*)c.take((R + 255) / 256 * 256 * 8);
   w.total = (c.off + 255) & ~(size_t)255;
   return w;
 }
@@ -164,6 +186,7 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
   TRY(ln(w.X, D, nullptr, m->lnpre_g, m->lnpre_b, nullptr, 0, w.X, D, R, D, pr, stream));
 
   // ---- blocks (VitaCLIP_vision_encoder.py:115-121, VitaCLIP_vision_encoder_utils.py:155-203)
+  bool folded_in = false;   // Xn / STATS already hold this block's un-normalised input and its row statistics
   for (int i = 0; i < m->layers; ++i) {
     const gava_vision_layer& L = m->layer[i];
     TRY(keep(1 + i));
@@ -191,11 +214,23 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
     TRY(gava::side_ln(L.global_prompts, L.local_prompts, w.CP, w.SUMM, L.ln1_g, L.ln1_b, w.SIDEn, G, Tm, BT, D, pr, (hipStream_t)ss));
     TRY(gemm(w.SIDEn, D, wqkv + (long)D * D, D, L.b_qkv + D, w.SIDEKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, ss));
     if (two && hipEventRecord(g_side.join[i], g_side.s) != hipSuccess) return GAVA_ELAUNCH;
-    gava::set_gemm_cu_reserve(two ? 8 : 0);   // the persistent QKV GEMM leaves 8 CUs to the side kernels
-    // main path
-    TRY(ln(w.X, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
+    gava::set_gemm_cu_reserve(two ? side_cus() : 0);   // the persistent QKV GEMM leaves side_cus() CUs to the side kernels
+    // main path.  LayerNorm folding (inference only, when the model carries the folded weights): norm2 of every block
+    // but the last and norm1 of blocks 1..layers-2 are not launched; the producing GEMM (out_proj / fc2 of the block
+    // before) leaves a 16-bit copy of x in Xn plus row-sum partials, gava_row_stats makes (mean, rstd) of them and the
+    // consuming GEMM (fc1 / qkv) applies the normalisation in its epilogue.
+    const bool not_last = i + 1 < m->layers;
+    const bool fold2 = !saved_x && not_last && L.w_fc1_fold && D % 64 == 0;
+    const bool fold1 = folded_in;                                                    // set by the previous block's fc2
+    const bool fold1_next = !saved_x && i + 2 < m->layers && m->layer[i + 1].w_qkv_fold && D % 64 == 0;
+    Fold produce; produce.x16 = w.Xn; produce.ld_x16 = D; produce.rowsum = w.RSUM;
+    if (!fold1) TRY(ln(w.X, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
     const unsigned short* sk = (const unsigned short*)w.SIDEKV;
-    if (i + 1 < m->layers) {
+    if (not_last) {
+      if (fold1) {
+        Fold c; c.stats = w.STATS; c.s = L.qkv_fold_s; c.t = L.qkv_fold_t;
+        TRY(gemm(w.Xn, D, L.w_qkv_fold, D, nullptr, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, &c));
+      } else
       TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
       gava::set_gemm_cu_reserve(0);
       if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
@@ -209,10 +244,23 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
         a.n_g = G; a.T = Tm; a.has_summary = 1; a.prec = pr;
         TRY(gava_attention(&a, stream));
       }
-      TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D));
-      TRY(ln(w.X, D, nullptr, L.ln2_g, L.ln2_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
-      TRY(gemm(w.Xn, D, L.w_fc1, D, L.b_fc1, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream));
-      TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D));
+      if (fold2) {
+        TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
+        TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
+        Fold c; c.stats = w.STATS; c.s = L.fc1_fold_s; c.t = L.fc1_fold_t;
+        TRY(gemm(w.Xn, D, L.w_fc1_fold, D, nullptr, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, &c));
+      } else {
+        TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D));
+        TRY(ln(w.X, D, nullptr, L.ln2_g, L.ln2_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
+        TRY(gemm(w.Xn, D, L.w_fc1, D, L.b_fc1, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream));
+      }
+      if (fold1_next) {
+        TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
+        TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
+      } else {
+        TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D));
+      }
+      folded_in = fold1_next;
     } else {
       // Last block: only the CLS row of each frame reaches the outputs (VitaCLIP_vision_encoder.py:126
       // takes x[:,0]; the summary token comes from the prompt path above).  Keys/values are still
@@ -311,7 +359,7 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
     TRY(gava::side_ln(L.global_prompts, L.local_prompts, w.CP, w.SUMM, L.ln1_g, L.ln1_b, w.SIDEn, G, Tm, BT, D, pr, (hipStream_t)ss));
     TRY(gemm(w.SIDEn, D, wqkv + (long)D * D, D, L.b_qkv + D, SKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, ss));
     if (two && hipEventRecord(g_side.join[i], g_side.s) != hipSuccess) return GAVA_ELAUNCH;
-    gava::set_gemm_cu_reserve(two ? 8 : 0);
+    gava::set_gemm_cu_reserve(two ? side_cus() : 0);
     TRY(ln(Xin, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
     if (i + 1 == m->layers && sv->last_q && sv->last_x1 && sv->last_pre) {
       // Last block, as in the inference driver: keys/values for every row, queries / out_proj / MLP for the B*T CLS

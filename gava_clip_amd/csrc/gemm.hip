@@ -38,6 +38,9 @@ struct GemmParams {
   const unsigned short* aux;   // EPI_H16_QGELU_BWD: pre-activations, laid out as out
   int aux_f16;                 // ... stored as fp16 (else bf16), independent of the operand precision
   unsigned short* aux_out;     // EPI_H16_QGELU: optional copy of the pre-activation (training forward)
+  // LayerNorm folding: producer (EPI_F32) extras and consumer (EPI_H16*) inputs, see gava_hip.h
+  unsigned short* x16; long ldx16; float2* rowsum;
+  const float2* fstats; const float* fs; const float* ft;
   int M, N, K;
   int scale_cols; float scale;
   const float* pos; const float* time; int n_patches; int T;
@@ -243,6 +246,25 @@ void gemm_kernel(const GemmParams p) {
   // i.e. for the previous row's stores) in every `m < M` block below
 #pragma unroll
   for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(bj[j].x), "v"(bj[j].y), "v"(bj[j].z), "v"(bj[j].w));
+  // folded LayerNorm (consumer): out = rstd * (acc - mean * s_n) + t_n; t_n arrives in the bias registers
+  constexpr bool CAN_FOLD = EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU;
+  const bool fold = CAN_FOLD && p.fstats != nullptr;
+  float4 sj[4];
+  float2 rs[4];
+  if (fold) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sj[j] = *reinterpret_cast<const float4*>(p.fs + nbase + j * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wr * 64 + i * 16 + fr;
+      rs[i] = p.fstats[m < p.M ? m : p.M - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      asm volatile("" ::"v"(sj[j].x), "v"(sj[j].y), "v"(sj[j].z), "v"(sj[j].w));
+      asm volatile("" ::"v"(rs[j].x), "v"(rs[j].y));
+    }
+  }
 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -257,11 +279,17 @@ void gemm_kernel(const GemmParams p) {
       posr = p.pos + (long)(1 + pp) * p.N;
       timr = p.time + (long)(frame % p.T) * p.N;
     }
+    float ps1 = 0.f, ps2 = 0.f;   // producer side of the folding: this lane's share of sum x, sum x^2 of the row
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = nbase + j * 16;
       float v0 = acc[i][j][0] + bj[j].x, v1 = acc[i][j][1] + bj[j].y;
       float v2 = acc[i][j][2] + bj[j].z, v3 = acc[i][j][3] + bj[j].w;
+      if (fold) {
+        const float r = rs[i].y, mr = -rs[i].x * rs[i].y;
+        v0 = fmaf(acc[i][j][0], r, fmaf(mr, sj[j].x, bj[j].x)); v1 = fmaf(acc[i][j][1], r, fmaf(mr, sj[j].y, bj[j].y));
+        v2 = fmaf(acc[i][j][2], r, fmaf(mr, sj[j].z, bj[j].z)); v3 = fmaf(acc[i][j][3], r, fmaf(mr, sj[j].w, bj[j].w));
+      }
       if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU || EPI == GAVA_EPI_H16_QGELU_BWD) {
         if (EPI == GAVA_EPI_H16) {
           if (n < p.scale_cols) { v0 *= p.scale; v1 *= p.scale; v2 *= p.scale; v3 *= p.scale; }
@@ -286,12 +314,23 @@ void gemm_kernel(const GemmParams p) {
       } else if (EPI == GAVA_EPI_F32) {
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) =
             make_float4(v0, v1, v2, v3);
+        if (p.x16) {
+          *reinterpret_cast<uint2*>(p.x16 + orow * p.ldx16 + n) = pack4<P>(v0, v1, v2, v3);
+          ps1 += (v0 + v1) + (v2 + v3);
+          ps2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+        }
       } else {  // GAVA_EPI_F32_PATCH
         const float4 pr = *reinterpret_cast<const float4*>(posr + n);
         const float4 tr = *reinterpret_cast<const float4*>(timr + n);
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) =
             make_float4(v0 + pr.x + tr.x, v1 + pr.y + tr.y, v2 + pr.z + tr.z, v3 + pr.w + tr.w);
       }
+    }
+    if (EPI == GAVA_EPI_F32 && p.x16) {
+      // the 4 lanes that share this row (same fr, fg = 0..3) cover the wave's 64 columns: one partial per row and wave
+      ps1 += __shfl_xor(ps1, 16, 64); ps2 += __shfl_xor(ps2, 16, 64);
+      ps1 += __shfl_xor(ps1, 32, 64); ps2 += __shfl_xor(ps2, 32, 64);
+      if (fg == 0) p.rowsum[orow * (p.N / 64) + (n0 + wc * 64) / 64] = make_float2(ps1, ps2);
     }
   }
 }
@@ -342,7 +381,7 @@ int launch_tile(GemmParams gp, int epi, hipStream_t s) {
 //     64-byte fp32 contiguous per lane, whole 128-byte lines per 4 lanes, no cross-lane shuffles.
 //     The W tile uses its own bank swizzle (bits 1,4,5 of the row) that is conflict-free for
 //     that read pattern.
-template <class P, int EPI, bool RES, bool SPLIT>
+template <class P, int EPI, bool RES, bool SPLIT, bool FOLD = false>
 __global__ __launch_bounds__(512, 2)
 void gemm256_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NW = 8;
@@ -350,7 +389,12 @@ void gemm256_kernel(const GemmParams p) {
   constexpr int PPW = (BM + BN) / 8 / NW;                            // 8 glds per wave per stage
   constexpr int NSTORE = (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH) ? 32 : (SPLIT ? 48 : 16);
   constexpr bool ACC_RES = EPI == GAVA_EPI_F32 && RES;   // accumulators start at the residual tile
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  // folded LayerNorm (consumer side, see gava_hip.h): the tile's s_n (1 KiB) and its rows' (mean, rstd) pairs
+  // (2 KiB) ride with the first operand stage of the tile into a parity-indexed LDS block behind the ring
+  constexpr bool CAN_FOLD = FOLD;
+  constexpr int FOLD_BYTES = 3072;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (CAN_FOLD ? 2 * FOLD_BYTES : 0)];
+  constexpr bool fold = FOLD;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -403,6 +447,14 @@ void gemm256_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) piece(g & 1, kt, i);
   };
+  // waves 0..2 fetch the fold block of tile `tj` at (mm0, nn0); fold_stats holds tiles_m*256 rows (host contract)
+  auto fold_fetch = [&](int tj, int mm0, int nn0) {
+    if (CAN_FOLD && fold && wave < 3) {
+      const float* src_f = wave == 0 ? p.fs + nn0 + lane * 4
+                                     : reinterpret_cast<const float*>(p.fstats) + (size_t)(mm0 + (wave - 1) * 128 + lane * 2) * 2;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src_f), LDS_PTR(void, smem + 2 * STAGE + (tj & 1) * FOLD_BYTES + wave * 1024), 16, 0, 0);
+    }
+  };
 
   // fragment read offsets.  A rows: wr*128 + i*16 + fr, swizzle (row>>1)&7 = fr>>1.
   // W rows: wc*64 + 16*(fr>>2) + 4*j + (fr&3), swizzle ((row>>1)&1) | (((row>>4)&3)<<1) = ((fr>>1)&1) | ((fr>>2)<<1)
@@ -436,6 +488,7 @@ void gemm256_kernel(const GemmParams p) {
   }
   set_src(m0, n0);
   stage(0, 0);
+  fold_fetch(0, m0, n0);
   int counted = 0;   // the next wait may leave this wave's NSTORE (1) or 2*NSTORE (2: pre-activation copy) epilogue stores in flight
   // diagnostic stamps (gava_debug_set_buffer; tools/gemm_stamps.py): cycles in the vmcnt wait, the barrier,
   // the stage body and the epilogue
@@ -469,9 +522,26 @@ void gemm256_kernel(const GemmParams p) {
             tile_coords(j + 1, m0n, n0n);
             set_src(m0n, n0n);
             stage(g + 1, 0);
+            fold_fetch(j + 1, m0n, n0n);
           }
         }
       };
+      if (CAN_FOLD && fold && kt == 0) {
+        // accumulators start at -mean_m * s_n: the MFMAs then leave acc - mean * s, the epilogue scales by rstd
+        const char* fb = smem + 2 * STAGE + (j & 1) * FOLD_BYTES;
+        float4 sj[4];
+        float mu[8];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) sj[jj] = *reinterpret_cast<const float4*>(fb + (wc * 64 + 16 * fg + 4 * jj) * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mu[i] = *reinterpret_cast<const float*>(fb + 1024 + (wr * 128 + i * 16 + fr) * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            acc[i][jj] = (f32x4_t){-mu[i] * sj[jj].x, -mu[i] * sj[jj].y, -mu[i] * sj[jj].z, -mu[i] * sj[jj].w};
+        __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of the stage below this block (register pressure)
+      }
       if (wave < 4) issue_next();
       const char* cur = smem + (g & 1) * STAGE;
       s16x8_t wf0[4], wf1[4], a00[4], a01[4], a10[4], a11[4];
@@ -525,6 +595,18 @@ void gemm256_kernel(const GemmParams p) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) asm volatile("" ::"v"(bj[jj].x), "v"(bj[jj].y), "v"(bj[jj].z), "v"(bj[jj].w));
     const bool full = m0 + BM <= p.M;
+    // folded LayerNorm: out = rstd_m * acc + t_n (acc already holds x.W' - mean_m * s_n; t_n came in as the bias)
+    float rstd[CAN_FOLD ? 8 : 1];
+    if (CAN_FOLD && fold) {
+      // read by hand: left to the compiler these loads are merged with the `mu` reads of stage 0 and then live (spilled)
+      // across the whole k-loop, and a plain LDS read here would also be fenced with vmcnt(0) against the in-flight DMA
+      const unsigned fb = (unsigned)(size_t)LDS_PTR(char, smem) + 2 * STAGE + (j & 1) * FOLD_BYTES + 1024 + (wr * 128 + fr) * 8 + 4;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(rstd[i]) : "v"(fb), "n"(i * 128));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(rstd[i]));   // results are valid only after the wait
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int m = m0 + wr * 128 + i * 16 + fr;
@@ -543,6 +625,11 @@ void gemm256_kernel(const GemmParams p) {
         for (int jj = 0; jj < 4; ++jj) {
           v[4 * jj + 0] = acc[i][jj][0] + bj[jj].x; v[4 * jj + 1] = acc[i][jj][1] + bj[jj].y;
           v[4 * jj + 2] = acc[i][jj][2] + bj[jj].z; v[4 * jj + 3] = acc[i][jj][3] + bj[jj].w;
+          if (CAN_FOLD && fold) {
+            const float r = rstd[CAN_FOLD ? i : 0];
+            v[4 * jj + 0] = fmaf(acc[i][jj][0], r, bj[jj].x); v[4 * jj + 1] = fmaf(acc[i][jj][1], r, bj[jj].y);
+            v[4 * jj + 2] = fmaf(acc[i][jj][2], r, bj[jj].z); v[4 * jj + 3] = fmaf(acc[i][jj][3], r, bj[jj].w);
+          }
         }
         if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU || EPI == GAVA_EPI_H16_QGELU_BWD) {
           if (EPI == GAVA_EPI_H16) {
@@ -606,6 +693,22 @@ void gemm256_kernel(const GemmParams p) {
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
             *reinterpret_cast<float4*>(o + 4 * jj) = make_float4(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
+          if (EPI == GAVA_EPI_F32 && p.x16) {
+            // producer side of the LayerNorm folding: 16-bit copy of the row segment + its (sum x, sum x^2)
+            unsigned short* xo = p.x16 + orow * p.ldx16 + nb0;
+            float ps1 = 0.f, ps2 = 0.f;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const uint2 x = pack4<P>(v[8 * hh], v[8 * hh + 1], v[8 * hh + 2], v[8 * hh + 3]);
+              const uint2 y = pack4<P>(v[8 * hh + 4], v[8 * hh + 5], v[8 * hh + 6], v[8 * hh + 7]);
+              *reinterpret_cast<uint4*>(xo + 8 * hh) = make_uint4(x.x, x.y, y.x, y.y);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { ps1 += v[e]; ps2 += v[e] * v[e]; }
+            ps1 += __shfl_xor(ps1, 16, 64); ps2 += __shfl_xor(ps2, 16, 64);
+            ps1 += __shfl_xor(ps1, 32, 64); ps2 += __shfl_xor(ps2, 32, 64);
+            if (fg == 0) p.rowsum[orow * (p.N / 64) + (n0 + wc * 64) / 64] = make_float2(ps1, ps2);
+          }
         }
       }
       // next tile: its residual rows go straight into the accumulators just freed (all 32 loads in flight
@@ -620,7 +723,7 @@ void gemm256_kernel(const GemmParams p) {
     // a full tile issued exactly NSTORE stores per wave after the in-flight stage: they may stay in flight
     // over the next wait (ragged tiles store fewer, and the accumulator-residual loads add to the count:
     // those cases fall back to vmcnt(0)).
-    counted = (full && !ACC_RES && !(p.ablate & 4)) ? ((EPI == GAVA_EPI_H16_QGELU && p.aux_out) ? 2 : 1) : 0;
+    counted = (full && !ACC_RES && !(p.ablate & 4) && !(EPI == GAVA_EPI_F32 && p.x16)) ? ((EPI == GAVA_EPI_H16_QGELU && p.aux_out) ? 2 : 1) : 0;
     m0 = m0n; n0 = n0n;
   }
   if (stamp && lane == 0) {
@@ -948,10 +1051,16 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
   } while (0)
   switch (epi) {
     case GAVA_EPI_H16:
-      if (gp.split_out) GAVA_LAUNCH(GAVA_EPI_H16, false, true); else GAVA_LAUNCH(GAVA_EPI_H16, false, false);
+      if (gp.fstats) {   // folded LayerNorm: its own instantiation, the plain kernels stay as they were
+        if (KERN != 3 || gp.split_out) return GAVA_EINVAL;
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_H16, false, false, true>), grid, block, 0, s, gp);
+      } else if (gp.split_out) GAVA_LAUNCH(GAVA_EPI_H16, false, true); else GAVA_LAUNCH(GAVA_EPI_H16, false, false);
       break;
     case GAVA_EPI_H16_QGELU:
-      if (gp.split_out) GAVA_LAUNCH(GAVA_EPI_H16_QGELU, false, true); else GAVA_LAUNCH(GAVA_EPI_H16_QGELU, false, false);
+      if (gp.fstats) {
+        if (KERN != 3 || gp.split_out) return GAVA_EINVAL;
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_H16_QGELU, false, false, true>), grid, block, 0, s, gp);
+      } else if (gp.split_out) GAVA_LAUNCH(GAVA_EPI_H16_QGELU, false, true); else GAVA_LAUNCH(GAVA_EPI_H16_QGELU, false, false);
       break;
     case GAVA_EPI_F32:
       if (gp.resid) GAVA_LAUNCH(GAVA_EPI_F32, true, false); else GAVA_LAUNCH(GAVA_EPI_F32, false, false);
@@ -1010,6 +1119,9 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   if (a->split_out && a->epilogue != GAVA_EPI_H16 && a->epilogue != GAVA_EPI_H16_QGELU) return GAVA_EINVAL;
   if (a->epilogue == GAVA_EPI_H16_QGELU_BWD && (!a->aux || ((uintptr_t)a->aux & 15) || a->ldo % 8 ||
                                                (a->aux_prec != GAVA_PREC_F16 && a->aux_prec != GAVA_PREC_BF16))) return GAVA_EINVAL;
+  if (a->x16_out && (a->epilogue != GAVA_EPI_F32 || !a->rowsum_out || a->ld_x16 % 8 || ((uintptr_t)a->x16_out & 15) || ((uintptr_t)a->rowsum_out & 7))) return GAVA_EINVAL;
+  if (a->fold_stats && ((a->epilogue != GAVA_EPI_H16 && a->epilogue != GAVA_EPI_H16_QGELU) || a->bias || !a->fold_s || !a->fold_t ||
+                        (((uintptr_t)a->fold_stats | (uintptr_t)a->fold_s | (uintptr_t)a->fold_t) & 15))) return GAVA_EINVAL;
   if (a->aux_out && (a->epilogue != GAVA_EPI_H16_QGELU || a->split_out || ((uintptr_t)a->aux_out & 15) || a->ldo % 8)) return GAVA_EINVAL;
   if (a->epilogue == GAVA_EPI_F32 && a->resid && (a->ldr % 4 || ((uintptr_t)a->resid & 15))) return GAVA_EINVAL;
   if (a->epilogue == GAVA_EPI_F32_PATCH &&
@@ -1020,6 +1132,9 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.bias = a->bias; gp.out = a->out; gp.ldo = a->ldo;
   gp.resid = a->resid; gp.ldr = a->ldr;
   gp.aux = (const unsigned short*)a->aux; gp.aux_f16 = a->aux_prec == GAVA_PREC_F16; gp.aux_out = (unsigned short*)a->aux_out;
+  gp.x16 = (unsigned short*)a->x16_out; gp.ldx16 = a->ld_x16; gp.rowsum = (float2*)a->rowsum_out;
+  gp.fstats = (const float2*)a->fold_stats; gp.fs = a->fold_s; gp.ft = a->fold_t;
+  if (a->fold_stats) gp.bias = a->fold_t;   // t_n takes the bias registers of the epilogue
   gp.M = a->M; gp.N = a->N; gp.K = a->K;
   gp.scale_cols = a->scale_cols; gp.scale = a->scale;
   gp.pos = a->pos; gp.time = a->time; gp.n_patches = a->n_patches; gp.T = a->T;

@@ -1,6 +1,7 @@
 // rowops.hip — HBM-bound row kernels: LayerNorm, conversions, token/prompt assembly, pooling,
 // similarity head.  One 64-lane wave owns one row (float4 per lane, fully coalesced 1 KiB per
 // wave instruction); statistics are reduced with cross-lane shuffles, no LDS.
+#include <cstdlib>
 #include "common.h"
 #include "internal.h"
 
@@ -260,7 +261,26 @@ __global__ void text_feature_kernel(const float* tn, float* tf, int C, int n_kv,
   }
 }
 
+// (mean, rstd) of each row from the GEMM epilogues' per-64-column partial sums, fixed summation order
+__global__ void row_stats_kernel(const float2* part, int slots, float inv_d, int rows, float2* stats) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < slots; ++k) { const float2 v = part[(long)r * slots + k]; s1 += v.x; s2 += v.y; }
+  const float mean = s1 * inv_d;
+  const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
+  stats[r] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+}
+
 }  // namespace
+
+extern "C" int gava_row_stats(const float* rowsum, int slots, int D, int rows, float* stats, gava_stream_t stream) {
+  if (!rowsum || !stats || slots <= 0 || D <= 0 || rows <= 0) return GAVA_EINVAL;
+  hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)rowsum, slots, 1.0f / (float)D, rows, (float2*)stats);
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 extern "C" int gava_layernorm(const gava_layernorm_args* a, gava_stream_t stream) {
@@ -321,7 +341,11 @@ static int g_cu_reserve = 0;
 namespace gava {
 unsigned long long* debug_buffer() { return g_debug_buffer; }
 void set_gemm_cu_reserve(int n) { g_cu_reserve = n; }
-int gemm_cu_reserve() { return g_cu_reserve; }
+int gemm_cu_reserve() {
+  // GAVA_CU_RESERVE (diagnostics, tools/side_probe.py): overrides what the drivers ask for
+  static const int forced = getenv("GAVA_CU_RESERVE") ? atoi(getenv("GAVA_CU_RESERVE")) : -1;
+  return forced >= 0 ? forced : g_cu_reserve;
+}
 }
 
 // ---- internal launchers used by the fused drivers -------------------------------------------

@@ -20,7 +20,7 @@ EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_vision_workspace_bytes", "gava_vision_forward", "gava_text_workspace_bytes",
            "gava_text_forward", "gava_similarity_head", "gava_convert_h16", "gava_debug_set_buffer",
            "gava_preprocess_clip", "gava_layernorm_backward", "gava_qgelu_backward", "gava_attention_backward",
-           "gava_text_forward_train", "gava_vision_forward_train", "gava_attention_backward_workspace_bytes", "gava_vision_forward_keep"]
+           "gava_text_forward_train", "gava_vision_forward_train", "gava_attention_backward_workspace_bytes", "gava_vision_forward_keep", "gava_row_stats"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 
@@ -32,7 +32,9 @@ class GemmArgs(C.Structure):
                 ("scale_cols", C.c_int), ("scale", C.c_float),
                 ("pos", _fp), ("time", _fp), ("n_patches", C.c_int), ("T", C.c_int),
                 ("frames", _fp), ("frame_size", C.c_int), ("patch", C.c_int), ("split_out", C.c_int),
-                ("aux", _vp), ("aux_prec", C.c_int), ("aux_out", _vp)]
+                ("aux", _vp), ("aux_prec", C.c_int), ("aux_out", _vp),
+                ("x16_out", _vp), ("ld_x16", C.c_int64), ("rowsum_out", _fp),
+                ("fold_stats", _fp), ("fold_s", _fp), ("fold_t", _fp)]
 
 
 class LayerNormArgs(C.Structure):
@@ -55,7 +57,8 @@ class VisionLayer(C.Structure):
     _fields_ = [(n, _vp) for n in (
         "w_qkv", "b_qkv", "w_out", "b_out", "w_fc1", "b_fc1", "w_fc2", "b_fc2",
         "ln1_g", "ln1_b", "ln2_g", "ln2_b", "w_cls", "b_cls", "sln_g", "sln_b",
-        "w_sqkv", "b_sqkv", "w_sout", "b_sout", "local_prompts", "global_prompts")]
+        "w_sqkv", "b_sqkv", "w_sout", "b_sout", "local_prompts", "global_prompts",
+        "w_qkv_fold", "qkv_fold_s", "qkv_fold_t", "w_fc1_fold", "fc1_fold_s", "fc1_fold_t")]
 
 
 class VisionModel(C.Structure):
@@ -161,6 +164,8 @@ def load():
     lib.gava_attention_backward.restype = C.c_int
     lib.gava_attention_backward_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.gava_attention_backward_workspace_bytes.restype = C.c_size_t
+    lib.gava_row_stats.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, _vp]
+    lib.gava_row_stats.restype = C.c_int
     lib.gava_vision_forward_keep.argtypes = [C.POINTER(VisionModel), _fp, _fp, _fp, C.POINTER(VisionSaved), _vp, C.c_size_t, _vp]
     lib.gava_vision_forward_keep.restype = C.c_int
     lib.gava_vision_forward_train.argtypes = [C.POINTER(VisionModel), _fp, _fp, _fp, _fp, _fp, _vp, C.c_size_t, _vp]
@@ -196,8 +201,10 @@ def h16_dtype(prec):
 
 def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0,
          pos=None, time=None, n_patches=0, T=0, M=None, split_out=False, frames=None, frame_size=0, patch=0, aux=None,
-         aux_prec=None, aux_out=None):
+         aux_prec=None, aux_out=None, x16_out=None, rowsum_out=None, fold_stats=None, fold_s=None, fold_t=None):
     a = GemmArgs()
+    a.x16_out, a.ld_x16, a.rowsum_out = ptr(x16_out), (x16_out.stride(0) if x16_out is not None else 0), ptr(rowsum_out)
+    a.fold_stats, a.fold_s, a.fold_t = ptr(fold_stats), ptr(fold_s), ptr(fold_t)
     a.aux, a.aux_out = ptr(aux), ptr(aux_out)
     a.aux_prec = prec if aux_prec is None else aux_prec
     a.A, a.lda, a.W, a.ldw = ptr(A), (A.stride(0) if A is not None else W.stride(0)), ptr(W), W.stride(0)
@@ -303,3 +310,11 @@ def attention_backward(q, k, v, dout, dq, dk, dv, *, batch, heads, n, prec, caus
     a.dq, a.dk, a.dv, a.ld_dqkv = ptr(dq), ptr(dk), ptr(dv), dk.stride(0)
     a.batch, a.heads, a.n, a.causal, a.prec, a.q_scale = batch, heads, n, int(causal), prec, q_scale
     check(load().gava_attention_backward(C.byref(a), stream_ptr()), "gava_attention_backward")
+
+
+def row_stats(rowsum, D):
+    """float2 partial sums [rows][slots] of the folding producers -> (mean, rstd) float2 [rows]."""
+    rows, slots = rowsum.shape[0], rowsum.shape[1]
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=rowsum.device)
+    check(load().gava_row_stats(ptr(rowsum), slots, D, rows, ptr(stats), stream_ptr()), "gava_row_stats")
+    return stats

@@ -401,6 +401,8 @@ class VitaCLIP(nn.Module):
         # independent; opt-in because a benchmark must not skip work.  Invalidated by any parameter update.
         self.cache_text_features = False
         self.text_on_side_stream = os.environ.get("GAVA_TEXT_STREAM", "1") != "0"
+        # inference: LayerNorm folded into the qkv / fc1 GEMMs (two row passes per block less); GAVA_LN_FOLD=0 turns it off
+        self.fold_layernorm = os.environ.get("GAVA_LN_FOLD", "1") != "0"
         self.trim_text_rows = os.environ.get("GAVA_TEXT_TRIM", "1") != "0"   # skip the rows behind the last EOT (see _pack)
         self.text_rows_per_prompt = text_context_length
         # training: keep the backward's activations (~21 GB at B = 64, T = 8) instead of recomputing them per block, as
@@ -437,8 +439,13 @@ class VitaCLIP(nn.Module):
             addr ^= p.data_ptr()
             if p.dim() >= 2 and not p.requires_grad and not any(k in name for k in self._PASS_THROUGH):
                 ver += p._version
+        if self.fold_layernorm:   # norm1 / norm2 affines and the qkv / fc1 biases are baked into the folded copies
+            for blk in self.visual.blocks:
+                for q in (blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias, blk.attn.q_proj.bias,
+                          blk.attn.k_proj.bias, blk.attn.v_proj.bias, blk.mlp.fc1.bias):
+                    ver += q._version
         ps = next(self.parameters())
-        return (self.prec, self.text_split_precision, self.trim_text_rows, ps.device, addr, ver)
+        return (self.prec, self.text_split_precision, self.trim_text_rows, self.fold_layernorm, ps.device, addr, ver)
 
     def _summary_weight_versions(self):
         """Versions of the only TRAINABLE weights that have 16-bit copies (summary_attn_layer projections): an optimizer
@@ -515,6 +522,18 @@ class VitaCLIP(nn.Module):
             L.w_fc2, L.b_fc2 = K(self._h16(blk.mlp.fc2.weight)), K(self._f32(blk.mlp.fc2.bias))
             L.ln1_g, L.ln1_b = K(self._f32(blk.norm1.weight)), K(self._f32(blk.norm1.bias))
             L.ln2_g, L.ln2_b = K(self._f32(blk.norm2.weight)), K(self._f32(blk.norm2.bias))
+            if self.fold_layernorm:
+                # LayerNorm folded into the consumer GEMM (inference driver): W' = h16(gamma * W),
+                # s = row sums of the ROUNDED W', t = W beta + b in fp32
+                wq = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).detach().float()
+                bq = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).detach().float()
+                for tag, w0, b0, nrm in (("qkv", wq, bq, blk.norm1), ("fc1", blk.mlp.fc1.weight.detach().float(),
+                                                                     blk.mlp.fc1.bias.detach().float(), blk.norm2)):
+                    gam, bet = nrm.weight.detach().float(), nrm.bias.detach().float()
+                    wf = self._h16(w0 * gam)
+                    setattr(L, f"w_{tag}_fold", K(wf))
+                    setattr(L, f"{tag}_fold_s", K(wf.float().sum(1).contiguous()))
+                    setattr(L, f"{tag}_fold_t", K((w0.double() @ bet.double() + b0.double()).float().contiguous()))
             L.w_cls, L.b_cls = K(self._h16(blk.cls_proj.weight)), K(self._f32(blk.cls_proj.bias))
             L.sln_g, L.sln_b = K(self._f32(blk.summary_ln.weight)), K(self._f32(blk.summary_ln.bias))
             w_sqkv_t.append(self._h16(torch.cat([s.q_proj.weight, s.k_proj.weight, s.v_proj.weight], 0)))

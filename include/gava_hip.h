@@ -80,6 +80,13 @@ typedef struct {
                                      * from an fp16 forward, gradients in bf16) */
   void* aux_out;                    /* EPI_H16_QGELU (training forward): also store the pre-activation acc + bias as
                                      * h16 [M][ldo] here; NULL = off */
+  /* LayerNorm folded into the NEXT GEMM ("LayerNorm folding").  Producer side, EPI_F32: besides out32 also
+   * store x16 = h16(out) [M][ld_x16] and, per row and 64-column group, the partial sums (sum x, sum x^2) as
+   * float2 rowsum[M][N/64].  gava_row_stats turns them into (mean, rstd).  Consumer side, EPI_H16 / EPI_H16_QGELU with
+   * A = x16 and W = h16(gamma * W): out = rstd_m * (acc - mean_m * fold_s[n]) + fold_t[n], fold_s[n] = sum_k W[n][k],
+   * fold_t[n] = sum_k beta[k] * W0[n][k] + bias[n] (bias must then be NULL). */
+  void* x16_out; int64_t ld_x16; float* rowsum_out;
+  const float* fold_stats; const float* fold_s; const float* fold_t;
 } gava_gemm_args;
 int gava_gemm(const gava_gemm_args* a, gava_stream_t stream);
 
@@ -137,6 +144,11 @@ typedef struct {                 /* one TransformerEncoderLayer, utils:93-203 */
   const void* w_sout; const float* b_sout;
   const float* local_prompts;              /* [T][D] fp32                                    */
   const float* global_prompts;             /* [G][D] fp32 (row i of visual.global_prompts)   */
+  /* Optional (all NULL = off): LayerNorm folded into the consumer GEMM, inference driver only (see gava_gemm_args).
+   * w_*_fold = h16(gamma * W) [N][D]; *_fold_s[n] = sum_k w_fold[n][k] (of the ROUNDED weight);
+   * *_fold_t[n] = sum_k beta[k] * W[n][k] + bias[n] in fp32.  qkv: norm1 of this block, fc1: norm2. */
+  const void* w_qkv_fold; const float* qkv_fold_s; const float* qkv_fold_t;
+  const void* w_fc1_fold; const float* fc1_fold_s; const float* fc1_fold_t;
 } gava_vision_layer;
 
 typedef struct {
@@ -260,6 +272,10 @@ size_t gava_attention_backward_workspace_bytes(int batch, int heads, int n_q);
 int gava_text_forward_train(const gava_text_model* m, const int32_t* tokens, const float* ctx,
                             const int32_t* eot_index, float* out, float* saved_x, void* workspace,
                             size_t workspace_bytes, gava_stream_t stream);
+
+/* (mean, rstd) per row from the producers' partial sums: rowsum float2 [rows][slots] -> stats float2 [rows], D columns,
+ * eps 1e-5, variance = E[x^2] - mean^2 in fp32 with a fixed summation order (deterministic). */
+int gava_row_stats(const float* rowsum, int slots, int D, int rows, float* stats, gava_stream_t stream);
 
 /* gava_vision_forward that also keeps what the backward recomputes from: saved_x fp32 [layers+2][B*T_in*(n+1)][D] =
  * the embedding before ln_pre, the input of every block, and the final residual stream. */

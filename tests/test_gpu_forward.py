@@ -218,3 +218,26 @@ def test_text_rows_behind_the_last_eot_are_dead_work():
         assert m.text_rows_per_prompt == 77
     assert (a - b).abs().max() <= 1e-6 * b.abs().max()
     assert (ta - tb).abs().max() <= 1e-6
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny", "c1"])
+def test_layernorm_folding_on_and_off_both_meet_the_golden(golden_dir, cfg_name):
+    """Inference folds norm1 / norm2 into the qkv / fc1 GEMMs (model.fold_layernorm, GAVA_LN_FOLD): both the folded and
+    the plain path meet the reference's golden logits within 1e-3 (relative to the largest logit) and agree with each
+    other to the rounding of the 16-bit operands."""
+    cfg, gname, T, S = (TINY, "tiny.npz", TINY.num_frames, TINY.input_size) if cfg_name == "tiny" else (VIT_B16_T8, "c1_b16.npz", 8, 224)
+    g = np.load(os.path.join(golden_dir, gname))
+    x = torch.from_numpy(synth.synth_clip(2, T, S)).cuda()
+    out = {}
+    for fold in (True, False):
+        m, _ = build(cfg)
+        m.fold_layernorm = fold
+        with torch.no_grad():
+            out[fold] = m(x)[0].cpu().numpy()
+        pk = m._pack()
+        assert bool(pk["vis_layers"][0].w_qkv_fold) == fold
+        assert rel_to_max(out[fold], g["logits"]) < 1e-3, fold
+    print(f"\n[{cfg_name}] logits rel-to-max: folded {rel_to_max(out[True], g['logits']):.3e} plain "
+          f"{rel_to_max(out[False], g['logits']):.3e} folded-vs-plain {rel_to_max(out[True], out[False]):.3e}")
+    assert rel_to_max(out[True], out[False]) < 1e-3
+    assert not np.array_equal(out[True], out[False])   # the folded path really ran

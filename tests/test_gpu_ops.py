@@ -281,3 +281,58 @@ def test_gemm_patch_embed_im2col_free(prec, size, patch, B, T):
     Xv = X.view(B * T, n + 1, D)
     assert torch.allclose(Xv[:, 1:], ref, rtol=1e-4, atol=1e-4)
     assert torch.all(Xv[:, 0] == 0)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,K_prod", [(777, 768), (5000, 768), (45000, 3072)])   # 128^2 / 128^2 / persistent 256^2 producer
+def test_layernorm_folded_into_the_next_gemm(prec, M, K_prod):
+    """Producer (EPI_F32 + residual) also emits x16 and per-64-column (sum, sum^2) partials; gava_row_stats turns them
+    into (mean, rstd); the consumer GEMM on raw x16 with gamma-scaled weights reproduces LN(x) @ W^T + b
+    (DESIGN.md "LayerNorm folding").  Reference: fp32 LayerNorm + fp32 GEMM on the same 16-bit operands."""
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    D = 768
+    A = rnd((M, K_prod), 1.0, 1).to(d).to(dt)
+    Wp = rnd((D, K_prod), K_prod ** -0.5, 2).to(d).to(dt)
+    bp = rnd((D,), 0.3, 3).to(d)
+    X = rnd((M, D), 1.0, 4).to(d)
+    x_ref = X + A.float() @ Wp.float().t() + bp
+    Mp = (M + 255) // 256 * 256
+    x16 = torch.zeros(Mp, D, dtype=dt, device=d)
+    rowsum = torch.zeros(Mp, D // 64, 2, dtype=torch.float32, device=d)
+    hip.gemm(A, Wp, bp, X, epilogue=hip.EPI_F32, prec=prec, resid=X, x16_out=x16, rowsum_out=rowsum)
+    assert torch.allclose(X, x_ref, rtol=1e-4, atol=1e-4)
+    assert torch.equal(x16[:M], X.to(dt))
+    assert torch.allclose(rowsum[:M, :, 0].sum(1), X.sum(1), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(rowsum[:M, :, 1].sum(1), (X * X).sum(1), rtol=1e-4, atol=1e-3)
+    stats = hip.row_stats(rowsum, D)
+    mean, var = X.mean(1), X.var(1, unbiased=False)
+    assert torch.allclose(stats[:M, 0], mean, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(stats[:M, 1], (var + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
+
+    gamma, beta = (1 + rnd((D,), 0.2, 5)).to(d), rnd((D,), 0.2, 6).to(d)
+    for N, epi in ((2304, hip.EPI_H16), (3072, hip.EPI_H16_QGELU), (256, hip.EPI_H16)):
+        W = rnd((N, D), D ** -0.5, 7).to(d)
+        b = rnd((N,), 0.3, 8).to(d)
+        Wf = (W * gamma).to(dt)                       # gamma folded into the weight, then rounded
+        fs = Wf.float().sum(1).contiguous()
+        ft = (W @ beta + b).contiguous()
+        out = torch.zeros(M, N, dtype=dt, device=d)
+        kw = dict(scale_cols=N // 2, scale=0.125) if epi == hip.EPI_H16 else {}
+        hip.gemm(x16[:M], Wf, None, out, epilogue=epi, prec=prec, fold_stats=stats, fold_s=fs, fold_t=ft, **kw)
+        # the same operands in fp32: LN of the fp32 row, but the GEMM sees the 16-bit x and the 16-bit folded weight
+        xh = x16[:M].float()
+        r = (stats[:M, 1:2] * (xh @ Wf.float().t() - stats[:M, 0:1] * fs)) + ft
+        if epi == hip.EPI_H16:
+            r[:, :N // 2] *= 0.125
+        else:
+            r = r * torch.sigmoid(1.702 * r)
+        tol = 4 * EPS16[prec]
+        assert torch.allclose(out.float(), r, rtol=tol, atol=tol * 2), (N, epi)
+        # and against the unfolded definition (16-bit rounding of x and gamma*W is the only difference)
+        full = torch.nn.functional.layer_norm(X, (D,), gamma, beta) @ W.t() + b
+        if epi == hip.EPI_H16:
+            full[:, :N // 2] *= 0.125
+        else:
+            full = full * torch.sigmoid(1.702 * full)
+        assert (out.float() - full).abs().max() < 40 * EPS16[prec] * full.abs().max()

@@ -43,6 +43,25 @@ elif a.which == "qkv":
 elif a.which == "out":
     A, W, b, O = rn(R, D), rn(D, D, scale=D ** -0.5), rn(D, dtype=torch.float32), rn(R, D, dtype=torch.float32)
     fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32, prec=prec, resid=O); fl = 2.0 * R * D * D
+elif a.which in ("fc1fold", "qkvfold"):      # consumers of the LayerNorm folding
+    N = F if a.which == "fc1fold" else 3 * D
+    Rp = (R + 255) // 256 * 256
+    A, W, O = rn(R, D), rn(N, D, scale=D ** -0.5), torch.empty(R, N, dtype=dt, device=d)
+    st = torch.cat([rn(Rp, 1, scale=0.1, dtype=torch.float32), 1 + rn(Rp, 1, scale=0.1, dtype=torch.float32).abs()], 1).contiguous()
+    fs, ft = W.float().sum(1).contiguous(), rn(N, dtype=torch.float32)
+    epi = hip.EPI_H16_QGELU if a.which == "fc1fold" else hip.EPI_H16
+    kw = {} if a.which == "fc1fold" else dict(scale_cols=D, scale=0.125)
+    fn = lambda: hip.gemm(A, W, None, O, epilogue=epi, prec=prec, fold_stats=st, fold_s=fs, fold_t=ft, **kw); fl = 2.0 * R * N * D
+elif a.which in ("fc2fold", "outfold"):      # producers: fp32 residual stream + x16 copy + row-sum partials
+    K = F if a.which == "fc2fold" else D
+    Rp = (R + 255) // 256 * 256
+    A, W, b, O = rn(R, K), rn(D, K, scale=K ** -0.5), rn(D, dtype=torch.float32), rn(R, D, dtype=torch.float32)
+    x16, rsum = torch.empty(Rp, D, dtype=dt, device=d), torch.empty(Rp, D // 64, 2, dtype=torch.float32, device=d)
+    fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32, prec=prec, resid=O, x16_out=x16, rowsum_out=rsum); fl = 2.0 * R * K * D
+elif a.which == "rowstats":
+    Rp = (R + 255) // 256 * 256
+    rsum = torch.randn(Rp, D // 64, 2, device=d, generator=g).abs()
+    fn = lambda: hip.row_stats(rsum, D); fl = 0.0
 elif a.which == "patch":
     n, Kp = 196, 768
     x = torch.randn(a.B, 3, T, 224, 224, device=d, generator=g)
