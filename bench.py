@@ -103,7 +103,7 @@ def event_time_ms(fn, iters=10, warmup=3):
     return e0.elapsed_time(e1) / iters
 
 
-def kernel_table(cfg, B, prec):
+def kernel_table(cfg, B, prec, fold=False):
     """Stand-alone timings of the per-layer kernels at this config's shapes (through the C ABI)."""
     from gava_clip_amd import hip
     dt = hip.h16_dtype(prec)
@@ -144,6 +144,24 @@ def kernel_table(cfg, B, prec):
         2.0 * R * F * D, R * D * 2 + R * F * 2 + F * D * 2)
     add("gemm fc2  [R,F]x[D,F] +res f32", lambda: hip.gemm(HID, W2, b2, X, epilogue=hip.EPI_F32, prec=prec, resid=X),
         2.0 * R * D * F, R * F * 2 + R * D * 8 + D * F * 2)
+    if fold:
+        # the forms the inference forward launches when LayerNorm is folded into the consumer GEMMs (model.fold_layernorm)
+        Rp = (R + 255) // 256 * 256
+        rsum = torch.zeros(Rp, D // 64, 2, dtype=torch.float32, device=d)
+        stats = torch.cat([rn(Rp, 1, scale=0.1, dtype=torch.float32), 1 + rn(Rp, 1, scale=0.1, dtype=torch.float32).abs()], 1).contiguous()
+        s1, t1 = W1.float().sum(1).contiguous(), rn(F, dtype=torch.float32)
+        sq, tq = Wqkv.float().sum(1).contiguous(), rn(3 * D, dtype=torch.float32)
+        add("gemm qkv  folded-LN consumer", lambda: hip.gemm(Xn, Wqkv, None, QKV, epilogue=hip.EPI_H16, prec=prec, scale_cols=D, scale=0.125,
+                                                            fold_stats=stats, fold_s=sq, fold_t=tq),
+            2.0 * R * 3 * D * D, R * D * 2 + R * 3 * D * 2 + 3 * D * D * 2 + R * 8)
+        add("gemm out  +res f32 +x16 +row sums", lambda: hip.gemm(MIX, Wo, bo, X, epilogue=hip.EPI_F32, prec=prec, resid=X, x16_out=Xn, rowsum_out=rsum),
+            2.0 * R * D * D, R * D * 2 + R * D * 10 + D * D * 2 + R * (D // 64) * 8)
+        add("gemm fc1  folded-LN consumer, qgelu h16", lambda: hip.gemm(Xn, W1, None, HID, epilogue=hip.EPI_H16_QGELU, prec=prec,
+                                                                       fold_stats=stats, fold_s=s1, fold_t=t1),
+            2.0 * R * F * D, R * D * 2 + R * F * 2 + F * D * 2 + R * 8)
+        add("gemm fc2  +res f32 +x16 +row sums", lambda: hip.gemm(HID, W2, b2, X, epilogue=hip.EPI_F32, prec=prec, resid=X, x16_out=Xn, rowsum_out=rsum),
+            2.0 * R * D * F, R * F * 2 + R * D * 10 + D * F * 2 + R * (D // 64) * 8)
+        add("row stats (sum, sum^2) -> (mean, rstd)", lambda: hip.row_stats(rsum, D), 0, R * (D // 64) * 8 + R * 8)
     return rows
 
 
@@ -237,15 +255,17 @@ def main():
     }
     if rank == 0 and not a.no_kernels:
         log("stand-alone kernel timings")
-        rows = kernel_table(cfg, B, model.prec)
+        fold = bool(getattr(model, "fold_layernorm", False))
+        rows = kernel_table(cfg, B, model.prec, fold=fold)
         out["kernels"] = [{k: r[k] for k in ("kernel", "ms", "tflops", "gbps")} for r in rows]
-        fc1 = next(r for r in rows if r["kernel"].startswith("gemm fc1"))
+        # the roofline kernel is the fc1 GEMM in the form the forward launches it (LayerNorm folded into it or not)
+        fc1 = next(r for r in rows if r["kernel"].startswith("gemm fc1  folded" if fold else "gemm fc1"))
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")   # HBM bytes/launch from the committed PMC passes
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("gemm_fc1_bytes_per_launch")
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm256_kernel<PrecF16|PrecBF16, EPI_H16_QGELU> (vision fc1, M=%d N=%d K=%d)" % (
-                               B * cfg.num_frames * cfg.tokens_main, cfg.mlp_dim, cfg.feature_dim),
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm256_kernel<PrecF16|PrecBF16, EPI_H16_QGELU%s> (vision fc1, M=%d N=%d K=%d)" % (
+                               ", FOLD" if fold else "", B * cfg.num_frames * cfg.tokens_main, cfg.mlp_dim, cfg.feature_dim),
                            "achieved": fc1["tflops"], "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(fc1["tflops"] / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
                            "flops_per_launch": fc1["flops"], "ms_per_launch": fc1["ms"]}

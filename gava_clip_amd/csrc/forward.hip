@@ -34,9 +34,11 @@ SideStream g_side;
 // 8 or 16 CUs left out a 128-workgroup kernel on the second stream still waits for the GEMM's first workgroups to retire
 // (0.23 ms instead of 0.01 ms) - workgroups are dealt round-robin to the XCDs' shader engines and the dispatch blocks on
 // the first engine without a free CU; with 32 (one CU per engine) it runs at its stand-alone speed and the GEMM is 4 % slower.
-int side_cus() {
-  static const int n = getenv("GAVA_SIDE_CUS") ? atoi(getenv("GAVA_SIDE_CUS")) : 32;
-  return n;
+// When LN1 runs before the QKV GEMM most of the prompt path finishes beside LN1 and only its tail waits: 8 is then the
+// better trade (23.85 vs 24.0 ms per forward); with LN1 folded away the whole path sits beside the GEMM: 32 (23.4 vs 23.75).
+int side_cus(bool ln1_folded) {
+  static const int forced = getenv("GAVA_SIDE_CUS") ? atoi(getenv("GAVA_SIDE_CUS")) : -1;
+  return forced >= 0 ? forced : (ln1_folded ? 32 : 8);
 }
 
 struct Carver {
@@ -214,7 +216,7 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
     TRY(gava::side_ln(L.global_prompts, L.local_prompts, w.CP, w.SUMM, L.ln1_g, L.ln1_b, w.SIDEn, G, Tm, BT, D, pr, (hipStream_t)ss));
     TRY(gemm(w.SIDEn, D, wqkv + (long)D * D, D, L.b_qkv + D, w.SIDEKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, ss));
     if (two && hipEventRecord(g_side.join[i], g_side.s) != hipSuccess) return GAVA_ELAUNCH;
-    gava::set_gemm_cu_reserve(two ? side_cus() : 0);   // the persistent QKV GEMM leaves side_cus() CUs to the side kernels
+    gava::set_gemm_cu_reserve(two ? side_cus(folded_in) : 0);   // the persistent QKV GEMM leaves side_cus() CUs to the side kernels
     // main path.  LayerNorm folding (inference only, when the model carries the folded weights): norm2 of every block
     // but the last and norm1 of blocks 1..layers-2 are not launched; the producing GEMM (out_proj / fc2 of the block
     // before) leaves a 16-bit copy of x in Xn plus row-sum partials, gava_row_stats makes (mean, rstd) of them and the
@@ -359,7 +361,7 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
     TRY(gava::side_ln(L.global_prompts, L.local_prompts, w.CP, w.SUMM, L.ln1_g, L.ln1_b, w.SIDEn, G, Tm, BT, D, pr, (hipStream_t)ss));
     TRY(gemm(w.SIDEn, D, wqkv + (long)D * D, D, L.b_qkv + D, SKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, ss));
     if (two && hipEventRecord(g_side.join[i], g_side.s) != hipSuccess) return GAVA_ELAUNCH;
-    gava::set_gemm_cu_reserve(two ? side_cus() : 0);
+    gava::set_gemm_cu_reserve(two ? side_cus(false) : 0);
     TRY(ln(Xin, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
     if (i + 1 == m->layers && sv->last_q && sv->last_x1 && sv->last_pre) {
       // Last block, as in the inference driver: keys/values for every row, queries / out_proj / MLP for the B*T CLS

@@ -20,6 +20,11 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// 1: set_src's lane-dependent terms are recomputed per tile instead of hoisted out of the tile loop (35 VGPRs less: the
+// FOLD kernels need that to stay spill-free; measured +1 % on fc2, neutral on fc1 / qkv).  0 = hoisted, for A/B builds.
+#ifndef GAVA_V3_RECOMPUTE_SRC
+#define GAVA_V3_RECOMPUTE_SRC 1
+#endif
 #ifndef GAVA_V3_PRIO
 #define GAVA_V3_PRIO 1
 #endif
@@ -389,10 +394,11 @@ void gemm256_kernel(const GemmParams p) {
   constexpr int PPW = (BM + BN) / 8 / NW;                            // 8 glds per wave per stage
   constexpr int NSTORE = (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH) ? 32 : (SPLIT ? 48 : 16);
   constexpr bool ACC_RES = EPI == GAVA_EPI_F32 && RES;   // accumulators start at the residual tile
-  // folded LayerNorm (consumer side, see gava_hip.h): the tile's s_n (1 KiB) and its rows' (mean, rstd) pairs
-  // (2 KiB) ride with the first operand stage of the tile into a parity-indexed LDS block behind the ring
+  // folded LayerNorm (consumer side, see gava_hip.h).  Every wave fetches, with the first operand stage of a tile, the
+  // (mean, rstd) pairs of ITS 128 rows (1 KiB) and s_n of ITS 64 columns (256 B) by LDS-DMA into a private, tile-parity
+  // indexed block behind the ring: no barrier is needed before it reads them back, only its own vmcnt.
   constexpr bool CAN_FOLD = FOLD;
-  constexpr int FOLD_BYTES = 3072;
+  constexpr int FOLD_WAVE = 1280, FOLD_BYTES = NW * FOLD_WAVE;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (CAN_FOLD ? 2 * FOLD_BYTES : 0)];
   constexpr bool fold = FOLD;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -424,17 +430,22 @@ void gemm256_kernel(const GemmParams p) {
 
   unsigned src[PPW];   // 32-bit element offsets from p.A / p.W (host guarantees they fit)
   auto set_src = [&](int m0, int n0) {
+    // the lane-dependent terms are recomputed per tile (a few dozen VALU) instead of being hoisted out of the tile loop:
+    // hoisted they cost 35 VGPRs, the FOLD kernels then spill, and a spill reload waits on vmcnt, i.e. on the whole
+    // operand prefetch in flight (measured: +9 % per stage)
+    int ln = lane;
+    if (FOLD || GAVA_V3_RECOMPUTE_SRC) asm volatile("" : "+v"(ln));
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int piece = wave + i * NW;                 // 0..31: A rows, 32..63: W rows
-      const int row = (piece & 31) * 8 + (lane >> 3);
+      const int row = (piece & 31) * 8 + (ln >> 3);
       if (i < PPW / 2) {
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int chunk = (ln & 7) ^ ((row >> 1) & 7);
         int gm = m0 + row;
         gm = gm < p.M ? gm : p.M - 1;
         src[i] = (unsigned)gm * (unsigned)p.lda + chunk * 8;
       } else {
-        const int chunk = (lane & 7) ^ (((row >> 1) & 1) | (((row >> 4) & 3) << 1));
+        const int chunk = (ln & 7) ^ (((row >> 1) & 1) | (((row >> 4) & 3) << 1));
         src[i] = (unsigned)(n0 + row) * (unsigned)p.ldw + chunk * 8;
       }
     }
@@ -447,15 +458,20 @@ void gemm256_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) piece(g & 1, kt, i);
   };
-  // waves 0..2 fetch the fold block of tile `tj` at (mm0, nn0); fold_stats holds tiles_m*256 rows (host contract)
+  // fold block of tile `tj` at (mm0, nn0); fold_stats holds tiles_m*256 rows (host contract)
   auto fold_fetch = [&](int tj, int mm0, int nn0) {
-    if (CAN_FOLD && fold && wave < 3) {
-      const float* src_f = wave == 0 ? p.fs + nn0 + lane * 4
-                                     : reinterpret_cast<const float*>(p.fstats) + (size_t)(mm0 + (wave - 1) * 128 + lane * 2) * 2;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src_f), LDS_PTR(void, smem + 2 * STAGE + (tj & 1) * FOLD_BYTES + wave * 1024), 16, 0, 0);
+    if (CAN_FOLD) {
+      // lane offsets recomputed at every use (the empty asm hides them from loop-invariant hoisting: hoisted, they are
+      // spilled, and a spill reload waits on vmcnt, i.e. on the whole operand prefetch)
+      unsigned l16 = lane * 16u, l4 = lane * 4u;
+      asm volatile("" : "+v"(l16), "+v"(l4));
+      char* fb = smem + 2 * STAGE + (tj & 1) * FOLD_BYTES + wave * FOLD_WAVE;
+      const char* st = reinterpret_cast<const char*>(p.fstats) + (size_t)(mm0 + wr * 128) * 8;
+      const char* ss = reinterpret_cast<const char*>(p.fs) + (size_t)(nn0 + wc * 64) * 4;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(st + l16), LDS_PTR(void, fb), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ss + l4), LDS_PTR(void, fb + 1024), 4, 0, 0);
     }
   };
-
   // fragment read offsets.  A rows: wr*128 + i*16 + fr, swizzle (row>>1)&7 = fr>>1.
   // W rows: wc*64 + 16*(fr>>2) + 4*j + (fr&3), swizzle ((row>>1)&1) | (((row>>4)&3)<<1) = ((fr>>1)&1) | ((fr>>2)<<1)
   const int swa = fr >> 1;
@@ -475,6 +491,34 @@ void gemm256_kernel(const GemmParams p) {
     for (int jj = 0; jj < 4; ++jj) acc[i][jj] = *reinterpret_cast<const f32x4_t*>(rp + 4 * jj);
   };
 
+  // accumulators of tile `tj` start at -mean_m * s_n: the MFMAs then leave x.W' - mean * s, the epilogue scales by rstd.
+  // LDS reads by hand: the compiler would fence plain ones with vmcnt(0) against the LDS-DMA in flight.
+  auto fold_init = [&](int tj) {
+    if (CAN_FOLD) {
+      const unsigned fb = (unsigned)(size_t)LDS_PTR(char, smem) + 2 * STAGE + (tj & 1) * FOLD_BYTES + wave * FOLD_WAVE;
+      unsigned a_s = (lane >> 4) * 64u, a_m = (lane & 15) * 8u;
+      asm volatile("" : "+v"(a_s), "+v"(a_m));   // see fold_fetch
+      a_s += fb; a_m += fb;
+      f32x4_t sj[4];
+      float mu[8];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sj[jj]) : "v"(a_s), "n"(1024 + jj * 16));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(mu[i]) : "v"(a_m), "n"(i * 128));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) asm volatile("" : "+v"(sj[jj]));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(mu[i]));
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          acc[i][jj] = (f32x4_t){-mu[i] * sj[jj][0], -mu[i] * sj[jj][1], -mu[i] * sj[jj][2], -mu[i] * sj[jj][3]};
+    }
+  };
+
   int m0, n0, m0n, n0n;
   tile_coords(0, m0, n0);
 #pragma unroll
@@ -488,7 +532,11 @@ void gemm256_kernel(const GemmParams p) {
   }
   set_src(m0, n0);
   stage(0, 0);
-  fold_fetch(0, m0, n0);
+  if (CAN_FOLD) {
+    fold_fetch(0, m0, n0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fold_init(0);
+  }
   int counted = 0;   // the next wait may leave this wave's NSTORE (1) or 2*NSTORE (2: pre-activation copy) epilogue stores in flight
   // diagnostic stamps (gava_debug_set_buffer; tools/gemm_stamps.py): cycles in the vmcnt wait, the barrier,
   // the stage body and the epilogue
@@ -526,22 +574,6 @@ void gemm256_kernel(const GemmParams p) {
           }
         }
       };
-      if (CAN_FOLD && fold && kt == 0) {
-        // accumulators start at -mean_m * s_n: the MFMAs then leave acc - mean * s, the epilogue scales by rstd
-        const char* fb = smem + 2 * STAGE + (j & 1) * FOLD_BYTES;
-        float4 sj[4];
-        float mu[8];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) sj[jj] = *reinterpret_cast<const float4*>(fb + (wc * 64 + 16 * fg + 4 * jj) * 4);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) mu[i] = *reinterpret_cast<const float*>(fb + 1024 + (wr * 128 + i * 16 + fr) * 8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-            acc[i][jj] = (f32x4_t){-mu[i] * sj[jj].x, -mu[i] * sj[jj].y, -mu[i] * sj[jj].z, -mu[i] * sj[jj].w};
-        __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of the stage below this block (register pressure)
-      }
       if (wave < 4) issue_next();
       const char* cur = smem + (g & 1) * STAGE;
       s16x8_t wf0[4], wf1[4], a00[4], a01[4], a10[4], a11[4];
@@ -596,20 +628,18 @@ void gemm256_kernel(const GemmParams p) {
     for (int jj = 0; jj < 4; ++jj) asm volatile("" ::"v"(bj[jj].x), "v"(bj[jj].y), "v"(bj[jj].z), "v"(bj[jj].w));
     const bool full = m0 + BM <= p.M;
     // folded LayerNorm: out = rstd_m * acc + t_n (acc already holds x.W' - mean_m * s_n; t_n came in as the bias)
-    float rstd[CAN_FOLD ? 8 : 1];
-    if (CAN_FOLD && fold) {
-      // read by hand: left to the compiler these loads are merged with the `mu` reads of stage 0 and then live (spilled)
-      // across the whole k-loop, and a plain LDS read here would also be fenced with vmcnt(0) against the in-flight DMA
-      const unsigned fb = (unsigned)(size_t)LDS_PTR(char, smem) + 2 * STAGE + (j & 1) * FOLD_BYTES + 1024 + (wr * 128 + fr) * 8 + 4;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(rstd[i]) : "v"(fb), "n"(i * 128));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(rstd[i]));   // results are valid only after the wait
+    // rstd of row i+1 is fetched (LDS, by hand: see fold_init) while row i is processed: two registers, not eight
+    float r_cur = 0.f, r_next = 0.f;
+    unsigned a_r = (lane & 15) * 8u + 4u;
+    if (CAN_FOLD) {
+      asm volatile("" : "+v"(a_r));
+      a_r += (unsigned)(size_t)LDS_PTR(char, smem) + 2 * STAGE + (j & 1) * FOLD_BYTES + wave * FOLD_WAVE;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r_cur) : "v"(a_r) : "memory");
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int m = m0 + wr * 128 + i * 16 + fr;
+      if (CAN_FOLD && i < 7) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r_next) : "v"(a_r), "n"((i + 1) * 128));
       if (m < p.M && !(p.ablate & 4)) {
         long orow = m;
         const float* posr = nullptr;
@@ -626,7 +656,7 @@ void gemm256_kernel(const GemmParams p) {
           v[4 * jj + 0] = acc[i][jj][0] + bj[jj].x; v[4 * jj + 1] = acc[i][jj][1] + bj[jj].y;
           v[4 * jj + 2] = acc[i][jj][2] + bj[jj].z; v[4 * jj + 3] = acc[i][jj][3] + bj[jj].w;
           if (CAN_FOLD && fold) {
-            const float r = rstd[CAN_FOLD ? i : 0];
+            const float r = r_cur;
             v[4 * jj + 0] = fmaf(acc[i][jj][0], r, bj[jj].x); v[4 * jj + 1] = fmaf(acc[i][jj][1], r, bj[jj].y);
             v[4 * jj + 2] = fmaf(acc[i][jj][2], r, bj[jj].z); v[4 * jj + 3] = fmaf(acc[i][jj][3], r, bj[jj].w);
           }
@@ -715,10 +745,20 @@ void gemm256_kernel(const GemmParams p) {
       // together, no temporaries, no wait inside the epilogue)
       if (ACC_RES && j + 1 < my_tiles) {
         load_resid(i, m0n, n0n);
-      } else {
+      } else if (!CAN_FOLD) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       }
+      if (CAN_FOLD && i < 7) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("v_mov_b32 %0, %1" : "=v"(r_cur) : "v"(r_next));
+      }
+    }
+    if (CAN_FOLD && j + 1 < my_tiles) {
+      // the next tile's fold block was issued before this epilogue's stores: it has landed once at most those are in flight
+      if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE <= 63 ? NSTORE : 0) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      fold_init(j + 1);
     }
     // a full tile issued exactly NSTORE stores per wave after the in-flight stage: they may stay in flight
     // over the next wait (ragged tiles store fewer, and the accumulator-residual loads add to the count:

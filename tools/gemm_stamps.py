@@ -19,6 +19,12 @@ if which == "fc2":
 elif which == "qkv":
     A, W, b, O = rn(R, D), rn(3 * D, D, scale=D ** -0.5), rn(3 * D, dtype=torch.float32), torch.empty(R, 3 * D, dtype=torch.float16, device="cuda")
     fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_H16, prec=0, scale_cols=D, scale=0.125)
+elif which == "fc1fold":   # fc1 with LayerNorm folded in (consumer side)
+    Rp = (R + 255) // 256 * 256
+    A, W, O = rn(R, D), rn(F, D, scale=D ** -0.5), torch.empty(R, F, dtype=torch.float16, device="cuda")
+    st = torch.cat([rn(Rp, 1, scale=0.1, dtype=torch.float32), 1 + rn(Rp, 1, scale=0.1, dtype=torch.float32).abs()], 1).contiguous()
+    fs_, ft_ = W.float().sum(1).contiguous(), rn(F, dtype=torch.float32)
+    fn = lambda: hip.gemm(A, W, None, O, epilogue=hip.EPI_H16_QGELU, prec=0, fold_stats=st, fold_s=fs_, fold_t=ft_)
 else:
     A, W, b, O = rn(R, D), rn(F, D, scale=D ** -0.5), rn(F, dtype=torch.float32), torch.empty(R, F, dtype=torch.float16, device="cuda")
     fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_H16_QGELU, prec=0)
