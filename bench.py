@@ -131,37 +131,48 @@ def kernel_table(cfg, B, prec, fold=False):
         rows.append(dict(kernel=name, ms=round(ms, 4), tflops=round(flops / ms / 1e9, 1) if flops else None,
                          gbps=round(bytes_ / ms / 1e6, 1), flops=flops, bytes=bytes_))
 
+    Rp = (R + 255) // 256 * 256
+    rsum = torch.zeros(Rp, D // 64, 2, dtype=torch.float32, device=d)
+    stats = torch.cat([rn(Rp, 1, scale=0.1, dtype=torch.float32), 1 + rn(Rp, 1, scale=0.1, dtype=torch.float32).abs()], 1).contiguous()
+    s1, t1 = W1.float().sum(1).contiguous(), rn(F, dtype=torch.float32)
+    sq, tq = Wqkv.float().sum(1).contiguous(), rn(3 * D, dtype=torch.float32)
+    plain = {
+        "qkv": ("gemm qkv  [R,D]x[3D,D] h16", lambda: hip.gemm(Xn, Wqkv, bq, QKV, epilogue=hip.EPI_H16, prec=prec, scale_cols=D, scale=0.125),
+                2.0 * R * 3 * D * D, R * D * 2 + R * 3 * D * 2 + 3 * D * D * 2),
+        "out": ("gemm out  [R,D]x[D,D] +res f32", lambda: hip.gemm(MIX, Wo, bo, X, epilogue=hip.EPI_F32, prec=prec, resid=X),
+                2.0 * R * D * D, R * D * 2 + R * D * 8 + D * D * 2),
+        "fc1": ("gemm fc1  [R,D]x[F,D] qgelu h16", lambda: hip.gemm(Xn, W1, b1, HID, epilogue=hip.EPI_H16_QGELU, prec=prec),
+                2.0 * R * F * D, R * D * 2 + R * F * 2 + F * D * 2),
+        "fc2": ("gemm fc2  [R,F]x[D,F] +res f32", lambda: hip.gemm(HID, W2, b2, X, epilogue=hip.EPI_F32, prec=prec, resid=X),
+                2.0 * R * D * F, R * F * 2 + R * D * 8 + D * F * 2)}
+    # the forms the inference forward launches when LayerNorm is folded into the consumer GEMMs (model.fold_layernorm)
+    folded = {
+        "qkv": ("gemm qkv  folded-LN consumer, h16", lambda: hip.gemm(Xn, Wqkv, None, QKV, epilogue=hip.EPI_H16, prec=prec, scale_cols=D,
+                                                                      scale=0.125, fold_stats=stats, fold_s=sq, fold_t=tq),
+                2.0 * R * 3 * D * D, R * D * 2 + R * 3 * D * 2 + 3 * D * D * 2 + R * 8),
+        "out": ("gemm out  +res f32 +x16 +row sums", lambda: hip.gemm(MIX, Wo, bo, X, epilogue=hip.EPI_F32, prec=prec, resid=X, x16_out=X16, rowsum_out=rsum),
+                2.0 * R * D * D, R * D * 2 + R * D * 10 + D * D * 2 + R * (D // 64) * 8),
+        "fc1": ("gemm fc1  folded-LN consumer, qgelu h16", lambda: hip.gemm(Xn, W1, None, HID, epilogue=hip.EPI_H16_QGELU, prec=prec,
+                                                                            fold_stats=stats, fold_s=s1, fold_t=t1),
+                2.0 * R * F * D, R * D * 2 + R * F * 2 + F * D * 2 + R * 8),
+        "fc2": ("gemm fc2  +res f32 +x16 +row sums", lambda: hip.gemm(HID, W2, b2, X, epilogue=hip.EPI_F32, prec=prec, resid=X, x16_out=X16, rowsum_out=rsum),
+                2.0 * R * D * F, R * F * 2 + R * D * 10 + D * F * 2 + R * (D // 64) * 8)}
+    X16 = torch.empty(R, D, dtype=dt, device=d)
+    first, second = (folded, plain) if fold else (plain, None)
+    # per-layer order of the forward; the kernels the forward launches come first, at the positions they always had
     add("layernorm f32->h16 [R,D]", lambda: hip.layernorm(X, gam, bet, out16=Xn, prec=prec), 0, R * D * 6)
-    add("gemm qkv  [R,D]x[3D,D] h16", lambda: hip.gemm(Xn, Wqkv, bq, QKV, epilogue=hip.EPI_H16, prec=prec, scale_cols=D, scale=0.125),
-        2.0 * R * 3 * D * D, R * D * 2 + R * 3 * D * 2 + 3 * D * D * 2)
+    add(*first["qkv"])
     add("attention (frame,head) 197q x %dk" % cfg.attn_keys(),
         lambda: hip.attention(QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:], MIX, batch=BT, heads=H, n_q=n1, n_kmain=n1, prec=prec,
                               side_k=side[:, :D], side_v=side[:, D:], n_g=G, T=T, has_summary=True),
         4.0 * BT * H * n1 * cfg.attn_keys() * 64, R * 3 * D * 2 + R * D * 2)
-    add("gemm out  [R,D]x[D,D] +res f32", lambda: hip.gemm(MIX, Wo, bo, X, epilogue=hip.EPI_F32, prec=prec, resid=X),
-        2.0 * R * D * D, R * D * 2 + R * D * 8 + D * D * 2)
-    add("gemm fc1  [R,D]x[F,D] qgelu h16", lambda: hip.gemm(Xn, W1, b1, HID, epilogue=hip.EPI_H16_QGELU, prec=prec),
-        2.0 * R * F * D, R * D * 2 + R * F * 2 + F * D * 2)
-    add("gemm fc2  [R,F]x[D,F] +res f32", lambda: hip.gemm(HID, W2, b2, X, epilogue=hip.EPI_F32, prec=prec, resid=X),
-        2.0 * R * D * F, R * F * 2 + R * D * 8 + D * F * 2)
+    add(*first["out"])
+    add(*first["fc1"])
+    add(*first["fc2"])
     if fold:
-        # the forms the inference forward launches when LayerNorm is folded into the consumer GEMMs (model.fold_layernorm)
-        Rp = (R + 255) // 256 * 256
-        rsum = torch.zeros(Rp, D // 64, 2, dtype=torch.float32, device=d)
-        stats = torch.cat([rn(Rp, 1, scale=0.1, dtype=torch.float32), 1 + rn(Rp, 1, scale=0.1, dtype=torch.float32).abs()], 1).contiguous()
-        s1, t1 = W1.float().sum(1).contiguous(), rn(F, dtype=torch.float32)
-        sq, tq = Wqkv.float().sum(1).contiguous(), rn(3 * D, dtype=torch.float32)
-        add("gemm qkv  folded-LN consumer", lambda: hip.gemm(Xn, Wqkv, None, QKV, epilogue=hip.EPI_H16, prec=prec, scale_cols=D, scale=0.125,
-                                                            fold_stats=stats, fold_s=sq, fold_t=tq),
-            2.0 * R * 3 * D * D, R * D * 2 + R * 3 * D * 2 + 3 * D * D * 2 + R * 8)
-        add("gemm out  +res f32 +x16 +row sums", lambda: hip.gemm(MIX, Wo, bo, X, epilogue=hip.EPI_F32, prec=prec, resid=X, x16_out=Xn, rowsum_out=rsum),
-            2.0 * R * D * D, R * D * 2 + R * D * 10 + D * D * 2 + R * (D // 64) * 8)
-        add("gemm fc1  folded-LN consumer, qgelu h16", lambda: hip.gemm(Xn, W1, None, HID, epilogue=hip.EPI_H16_QGELU, prec=prec,
-                                                                       fold_stats=stats, fold_s=s1, fold_t=t1),
-            2.0 * R * F * D, R * D * 2 + R * F * 2 + F * D * 2 + R * 8)
-        add("gemm fc2  +res f32 +x16 +row sums", lambda: hip.gemm(HID, W2, b2, X, epilogue=hip.EPI_F32, prec=prec, resid=X, x16_out=Xn, rowsum_out=rsum),
-            2.0 * R * D * F, R * F * 2 + R * D * 10 + D * F * 2 + R * (D // 64) * 8)
         add("row stats (sum, sum^2) -> (mean, rstd)", lambda: hip.row_stats(rsum, D), 0, R * (D // 64) * 8 + R * 8)
+        for k in ("qkv", "out", "fc1", "fc2"):   # the unfolded forms (training, GAVA_LN_FOLD=0), for comparison
+            add(*second[k])
     return rows
 
 

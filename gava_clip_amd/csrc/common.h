@@ -82,8 +82,25 @@ static __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static __device__ __forceinline__ float quick_gelu(float x) {
-  // x * sigmoid(1.702 x)  (VitaCLIP_vision_encoder_utils.py:18-20)
-  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+  // x * sigmoid(1.702 x)  (VitaCLIP_vision_encoder_utils.py:18-20); exp(-1.702 x) = exp2(x * (-1.702 log2 e)):
+  // one multiply in front of v_exp_f32 instead of the two that __expf(-1.702f * x) compiles to
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.4554669595930157f));
+}
+
+// two values at a time: the multiplies and the add become packed-fp32 instructions (v_pk_mul_f32 / v_pk_add_f32),
+// which matters in the GEMM epilogues - they are VALU-issue-bound (finding 6)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ void quick_gelu2(float& a, float& b) {
+#ifdef GAVA_QGELU_SCALAR   // A/B builds: the previous scalar form
+  a = a * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * a));
+  b = b * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * b));
+  return;
+#endif
+  const f32x2_t x = {a, b};
+  const f32x2_t t = x * (f32x2_t){-2.4554669595930157f, -2.4554669595930157f};
+  const f32x2_t d = (f32x2_t){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + (f32x2_t){1.0f, 1.0f};
+  const f32x2_t y = x * (f32x2_t){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  a = y.x; b = y.y;
 }
 
 static __device__ __forceinline__ float quick_gelu_grad(float x) {

@@ -300,7 +300,7 @@ void gemm_kernel(const GemmParams p) {
           if (n < p.scale_cols) { v0 *= p.scale; v1 *= p.scale; v2 *= p.scale; v3 *= p.scale; }
         } else if (EPI == GAVA_EPI_H16_QGELU) {
           if (p.aux_out) *reinterpret_cast<uint2*>(p.aux_out + orow * p.ldo + n) = pack4<P>(v0, v1, v2, v3);
-          v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3);
+          quick_gelu2(v0, v1); quick_gelu2(v2, v3);
         } else {
           const uint2 ax = *reinterpret_cast<const uint2*>(p.aux + orow * p.ldo + n);
           v0 *= quick_gelu_grad(aux_up((unsigned short)ax.x, p.aux_f16)); v1 *= quick_gelu_grad(aux_up((unsigned short)(ax.x >> 16), p.aux_f16));
@@ -678,7 +678,7 @@ void gemm256_kernel(const GemmParams p) {
               }
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = quick_gelu(v[e]);
+            for (int e = 0; e < 16; e += 2) quick_gelu2(v[e], v[e + 1]);
           } else {
             const unsigned short* axp = p.aux + orow * p.ldo + nb0;
             const uint4 a0 = *reinterpret_cast<const uint4*>(axp), a1 = *reinterpret_cast<const uint4*>(axp + 8);
@@ -957,7 +957,7 @@ void gemm256r_kernel(const GemmParams p) {
                 }
               } else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = quick_gelu(v[e]);
+                for (int e = 0; e < 16; e += 2) quick_gelu2(v[e], v[e + 1]);
               }
               unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + nb0;
               if (SPLIT) {
