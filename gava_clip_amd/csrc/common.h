@@ -75,6 +75,15 @@ static __device__ __forceinline__ void split4(float a, float b, float c, float d
                 c - P::up((unsigned short)hi.y), d - P::up((unsigned short)(hi.y >> 16)));
 }
 
+// x[l] + x[l ^ 16] + x[l ^ 32] + x[l ^ 48] in every lane, on the VALU: gfx950's v_permlane16_swap / v_permlane32_swap
+// instead of two dependent ds_bpermute round trips through the LDS pipe
+static __device__ __forceinline__ float sum_across_lane_groups(float x) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -25,6 +25,9 @@
 #ifndef GAVA_V3_RECOMPUTE_SRC
 #define GAVA_V3_RECOMPUTE_SRC 1
 #endif
+#ifndef GAVA_V3_NAT
+#define GAVA_V3_NAT 1   // 0: permuted column order also for the fp32-output kernels (A/B builds)
+#endif
 #ifndef GAVA_V3_PRIO
 #define GAVA_V3_PRIO 1
 #endif
@@ -333,8 +336,7 @@ void gemm_kernel(const GemmParams p) {
     }
     if (EPI == GAVA_EPI_F32 && p.x16) {
       // the 4 lanes that share this row (same fr, fg = 0..3) cover the wave's 64 columns: one partial per row and wave
-      ps1 += __shfl_xor(ps1, 16, 64); ps2 += __shfl_xor(ps2, 16, 64);
-      ps1 += __shfl_xor(ps1, 32, 64); ps2 += __shfl_xor(ps2, 32, 64);
+      ps1 = sum_across_lane_groups(ps1); ps2 = sum_across_lane_groups(ps2);
       if (fg == 0) p.rowsum[orow * (p.N / 64) + (n0 + wc * 64) / 64] = make_float2(ps1, ps2);
     }
   }
@@ -394,6 +396,15 @@ void gemm256_kernel(const GemmParams p) {
   constexpr int PPW = (BM + BN) / 8 / NW;                            // 8 glds per wave per stage
   constexpr int NSTORE = (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH) ? 32 : (SPLIT ? 48 : 16);
   constexpr bool ACC_RES = EPI == GAVA_EPI_F32 && RES;   // accumulators start at the residual tile
+  // Column layout of the accumulators.  16-bit outputs: W rows are read in permuted order so that a lane ends with 16
+  // consecutive columns (32 contiguous bytes, two b128 stores).  fp32 outputs (NAT): natural order, lane (fr, fg) holds
+  // columns 16*jj + 4*fg + r, so that the four lanes of a row write / read 64 contiguous bytes per instruction - with the
+  // permuted order every fp32 store and residual load touched 64 separate 16-byte pieces and the fc2 epilogue took
+  // 30-50 k cycles per tile (tools/gemm_stamps.py fc2), four times the QuickGELU epilogue of fc1.
+  constexpr bool NAT = GAVA_V3_NAT && (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH);
+  constexpr int CJ = NAT ? 16 : 4;        // column step between a lane's accumulators jj and jj+1
+  constexpr int CF = NAT ? 4 : 16;        // column step between the lane groups fg and fg+1
+  constexpr int WJ = NAT ? 2048 : 512;    // LDS byte step between the W fragments jj and jj+1
   // folded LayerNorm (consumer side, see gava_hip.h).  Every wave fetches, with the first operand stage of a tile, the
   // (mean, rstd) pairs of ITS 128 rows (1 KiB) and s_n of ITS 64 columns (256 B) by LDS-DMA into a private, tile-parity
   // indexed block behind the ring: no barrier is needed before it reads them back, only its own vmcnt.
@@ -445,7 +456,7 @@ void gemm256_kernel(const GemmParams p) {
         gm = gm < p.M ? gm : p.M - 1;
         src[i] = (unsigned)gm * (unsigned)p.lda + chunk * 8;
       } else {
-        const int chunk = (ln & 7) ^ (((row >> 1) & 1) | (((row >> 4) & 3) << 1));
+        const int chunk = (ln & 7) ^ (NAT ? ((row >> 1) & 7) : (((row >> 1) & 1) | (((row >> 4) & 3) << 1)));
         src[i] = (unsigned)(n0 + row) * (unsigned)p.ldw + chunk * 8;
       }
     }
@@ -475,9 +486,9 @@ void gemm256_kernel(const GemmParams p) {
   // fragment read offsets.  A rows: wr*128 + i*16 + fr, swizzle (row>>1)&7 = fr>>1.
   // W rows: wc*64 + 16*(fr>>2) + 4*j + (fr&3), swizzle ((row>>1)&1) | (((row>>4)&3)<<1) = ((fr>>1)&1) | ((fr>>2)<<1)
   const int swa = fr >> 1;
-  const int swb = ((fr >> 1) & 1) | ((fr >> 2) << 1);
+  const int swb = NAT ? (fr >> 1) : (((fr >> 1) & 1) | ((fr >> 2) << 1));
   const int a_off = (wr * 128 + fr) * 128;
-  const int w_off = A_BYTES + (wc * 64 + 16 * (fr >> 2) + (fr & 3)) * 128;
+  const int w_off = A_BYTES + (NAT ? (wc * 64 + fr) : (wc * 64 + 16 * (fr >> 2) + (fr & 3))) * 128;
   const int a_k0 = (fg ^ swa) << 4, a_k1 = ((4 + fg) ^ swa) << 4;
   const int w_k0 = (fg ^ swb) << 4, w_k1 = ((4 + fg) ^ swb) << 4;
 
@@ -486,9 +497,9 @@ void gemm256_kernel(const GemmParams p) {
   auto load_resid = [&](int i, int mm0, int nn0) {
     int m = mm0 + wr * 128 + i * 16 + fr;
     m = m < p.M ? m : p.M - 1;
-    const float* rp = p.resid + (long)m * p.ldr + nn0 + wc * 64 + 16 * fg;
+    const float* rp = p.resid + (long)m * p.ldr + nn0 + wc * 64 + CF * fg;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = *reinterpret_cast<const f32x4_t*>(rp + 4 * jj);
+    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = *reinterpret_cast<const f32x4_t*>(rp + CJ * jj);
   };
 
   // accumulators of tile `tj` start at -mean_m * s_n: the MFMAs then leave x.W' - mean * s, the epilogue scales by rstd.
@@ -578,7 +589,7 @@ void gemm256_kernel(const GemmParams p) {
       const char* cur = smem + (g & 1) * STAGE;
       s16x8_t wf0[4], wf1[4], a00[4], a01[4], a10[4], a11[4];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) wf0[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 512 + w_k0);
+      for (int jj = 0; jj < 4; ++jj) wf0[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * WJ + w_k0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) a00[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 2048 + a_k0);
 #pragma unroll
@@ -588,7 +599,7 @@ void gemm256_kernel(const GemmParams p) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[i][jj] = P::mfma(wf0[jj], a00[i], acc[i][jj]);
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) wf1[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 512 + w_k1);
+      for (int jj = 0; jj < 4; ++jj) wf1[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * WJ + w_k1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) a10[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 2048 + a_k1);
 #pragma unroll
@@ -617,11 +628,11 @@ void gemm256_kernel(const GemmParams p) {
     if (stamp) { const unsigned long long t = clock64(); tC += t - ts; ts = t; in_epi = true; }
     // ---- epilogue of tile j: lane holds out[m][n .. n+15], m = m0+wr*128+i*16+fr,
     //      n = n0 + wc*64 + 16*fg + 4*jj + r
-    const int nb0 = n0 + wc * 64 + 16 * fg;
+    const int nb0 = n0 + wc * 64 + CF * fg;
     float4 bj[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
-      bj[jj] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb0 + 4 * jj) : make_float4(0, 0, 0, 0);
+      bj[jj] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb0 + CJ * jj) : make_float4(0, 0, 0, 0);
     // One explicit use on the common path: the compiler waits for the bias HERE, once.  Without it every row
     // below (a basic block of its own behind `m < M`) re-waits with vmcnt(0), i.e. for the previous row's stores.
 #pragma unroll
@@ -715,28 +726,24 @@ void gemm256_kernel(const GemmParams p) {
           if (EPI == GAVA_EPI_F32_PATCH) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-              const float4 pr = *reinterpret_cast<const float4*>(posr + 4 * jj);
-              const float4 tr = *reinterpret_cast<const float4*>(timr + 4 * jj);
+              const float4 pr = *reinterpret_cast<const float4*>(posr + CJ * jj);
+              const float4 tr = *reinterpret_cast<const float4*>(timr + CJ * jj);
               v[4 * jj] += pr.x + tr.x; v[4 * jj + 1] += pr.y + tr.y; v[4 * jj + 2] += pr.z + tr.z; v[4 * jj + 3] += pr.w + tr.w;
             }
           }
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
-            *reinterpret_cast<float4*>(o + 4 * jj) = make_float4(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
+            *reinterpret_cast<float4*>(o + CJ * jj) = make_float4(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
           if (EPI == GAVA_EPI_F32 && p.x16) {
             // producer side of the LayerNorm folding: 16-bit copy of the row segment + its (sum x, sum x^2)
             unsigned short* xo = p.x16 + orow * p.ldx16 + nb0;
             float ps1 = 0.f, ps2 = 0.f;
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-              const uint2 x = pack4<P>(v[8 * hh], v[8 * hh + 1], v[8 * hh + 2], v[8 * hh + 3]);
-              const uint2 y = pack4<P>(v[8 * hh + 4], v[8 * hh + 5], v[8 * hh + 6], v[8 * hh + 7]);
-              *reinterpret_cast<uint4*>(xo + 8 * hh) = make_uint4(x.x, x.y, y.x, y.y);
-            }
+            for (int jj = 0; jj < 4; ++jj)   // natural column order: 8 bytes per lane, 32 contiguous bytes per row
+              *reinterpret_cast<uint2*>(xo + CJ * jj) = pack4<P>(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
 #pragma unroll
             for (int e = 0; e < 16; ++e) { ps1 += v[e]; ps2 += v[e] * v[e]; }
-            ps1 += __shfl_xor(ps1, 16, 64); ps2 += __shfl_xor(ps2, 16, 64);
-            ps1 += __shfl_xor(ps1, 32, 64); ps2 += __shfl_xor(ps2, 32, 64);
+            ps1 = sum_across_lane_groups(ps1); ps2 = sum_across_lane_groups(ps2);
             if (fg == 0) p.rowsum[orow * (p.N / 64) + (n0 + wc * 64) / 64] = make_float2(ps1, ps2);
           }
         }
@@ -1134,7 +1141,10 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   if (gp.N % 256 == 0 && gp.K >= 256 && fits32r && variant == 8) return launch_256<P, 8>(gp, epi, s);
   const bool fits32 = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
   const long tiles256 = (long)((gp.M + 255) / 256) * (gp.N / 256);
-  if (gp.N % 256 == 0 && fits32 && (gp.N >= 1536 || (gp.K >= 2048 && tiles256 >= 512) || variant == 3))
+  // ... and, since the fp32-output kernels use the natural column order (64 contiguous bytes per row and instruction in
+  // the residual loads and the stores), also for the shallow fp32 GEMM: out 0.251 vs 0.268 ms on the 128^2 kernel
+  if (gp.N % 256 == 0 && fits32 &&
+      (gp.N >= 1536 || (gp.K >= 2048 && tiles256 >= 512) || (epi == GAVA_EPI_F32 && tiles256 >= 512) || variant == 3))
     return launch_256<P, 3>(gp, epi, s);
   return launch_tile<P, 128, 128, 2>(gp, epi, s);
 }
