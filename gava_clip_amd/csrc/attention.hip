@@ -12,6 +12,7 @@
 // of its own query: 8-byte stores, row sum in-lane.
 // Vision "side" keys (global/local prompts, summary token) are gathered from a separate small
 // K/V matrix while staging, so prompt tokens are never materialised per frame.
+#include <cstdlib>
 #include "common.h"
 #include "internal.h"
 
@@ -28,7 +29,7 @@ struct AttnParams {
   unsigned long long* dbg;
 };
 
-template <class P, int NKT, bool CAUSAL>
+template <class P, int NKT, bool CAUSAL, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
   constexpr int KP = NKT * 16;
   constexpr int NIT = (KP * 8 + 255) / 256;          // staging tasks (16 B of K and of V) per thread
@@ -50,7 +51,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     return p.q + ((long)n * p.qbr + qrow) * p.ldq + h * 64 + 8 * fg;
   };
   s16x8_t q0 = {0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0;
-  if (wave < n_qt) {
+  s16x8_t qb0 = q0, qb1 = q0;   // PAIR: second query tile of the wave's pair
+  if (PAIR) {
+    if (2 * wave < n_qt) {
+      const unsigned short* qp = q_ptr(2 * wave);
+      q0 = *reinterpret_cast<const s16x8_t*>(qp);
+      q1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
+      const unsigned short* qq = q_ptr(2 * wave + 1);   // row index clamped: a tile beyond n_q computes garbage, stores nothing
+      qb0 = *reinterpret_cast<const s16x8_t*>(qq);
+      qb1 = *reinterpret_cast<const s16x8_t*>(qq + 32);
+    }
+  } else if (wave < n_qt) {
     const unsigned short* qp = q_ptr(wave);
     q0 = *reinterpret_cast<const s16x8_t*>(qp);
     q1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
@@ -95,6 +106,135 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
   const int tr_off = (4 * fg + (fr >> 2)) * LDS_ROW + (fr & 3) * 8;
   constexpr float LOG2E = 1.4426950408889634f;
 
+  if constexpr (PAIR) {
+    // Two query tiles per wave and pass: every K fragment and every transposed V fragment read from LDS feeds two MFMAs
+    // instead of one (the kernel is LDS- and VALU-bound, and the forward is power-capped: half the LDS traffic per
+    // query).  Tiles 2*pr and 2*pr+1; pairs are dealt round-robin to the 4 waves.
+    const int n_pairs = (n_qt + 1) >> 1;
+    for (int pr = wave; pr < n_pairs; pr += 4) {
+      const int qia = pr * 32 + fr, qib = qia + 16;
+      s16x8_t na0 = q0, na1 = q1, nb0 = qb0, nb1 = qb1;
+      if (pr + 4 < n_pairs) {
+        const unsigned short* qp = q_ptr(2 * (pr + 4));
+        na0 = *reinterpret_cast<const s16x8_t*>(qp);
+        na1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
+        const unsigned short* qq = q_ptr(2 * (pr + 4) + 1);
+        nb0 = *reinterpret_cast<const s16x8_t*>(qq);
+        nb1 = *reinterpret_cast<const s16x8_t*>(qq + 32);
+      }
+      f32x4_t sa[NKT], sb[NKT];
+      constexpr int QCH = NKT % 7 == 0 ? 7 : (NKT % 5 == 0 ? 5 : (NKT % 4 == 0 ? 4 : (NKT % 3 == 0 ? 3 : 2)));
+      static_assert(NKT % QCH == 0, "key tiles per batch");
+#pragma unroll
+      for (int c0 = 0; c0 < NKT; c0 += QCH) {
+        s16x8_t kf[QCH][2];
+#pragma unroll
+        for (int t = 0; t < QCH; ++t) {
+          const char* kr = Ks + ((c0 + t) * 16 + fr) * LDS_ROW + fg * 16;
+          kf[t][0] = *reinterpret_cast<const s16x8_t*>(kr);
+          kf[t][1] = *reinterpret_cast<const s16x8_t*>(kr + 64);
+        }
+#pragma unroll
+        for (int t = 0; t < QCH; ++t) {
+          f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f}, b = a;
+          a = P::mfma(kf[t][0], q0, a);
+          b = P::mfma(kf[t][0], qb0, b);
+          a = P::mfma(kf[t][1], q1, a);
+          b = P::mfma(kf[t][1], qb1, b);
+          sa[c0 + t] = a;
+          sb[c0 + t] = b;
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * QCH, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * QCH, 0);
+      }
+      float mxa = -INFINITY, mxb = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        if (kt * 16 + 16 > p.n_keys) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = kt * 16 + 4 * fg + r < p.n_keys;
+            sa[kt][r] = ok ? sa[kt][r] : -INFINITY;
+            sb[kt][r] = ok ? sb[kt][r] : -INFINITY;
+          }
+        }
+        mxa = fmaxf(fmaxf(mxa, sa[kt][0]), fmaxf(sa[kt][1], fmaxf(sa[kt][2], sa[kt][3])));
+        mxb = fmaxf(fmaxf(mxb, sb[kt][0]), fmaxf(sb[kt][1], fmaxf(sb[kt][2], sb[kt][3])));
+      }
+      mxa = fmaxf(mxa, __shfl_xor(mxa, 16, 64)); mxb = fmaxf(mxb, __shfl_xor(mxb, 16, 64));
+      mxa = fmaxf(mxa, __shfl_xor(mxa, 32, 64)); mxb = fmaxf(mxb, __shfl_xor(mxb, 32, 64));
+      const float mna = -mxa * LOG2E, mnb = -mxb * LOG2E;
+      float suma = 0.f, sumb = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ea = __builtin_amdgcn_exp2f(fmaf(sa[kt][r], LOG2E, mna));
+          const float eb = __builtin_amdgcn_exp2f(fmaf(sb[kt][r], LOG2E, mnb));
+          sa[kt][r] = ea; suma += ea;
+          sb[kt][r] = eb; sumb += eb;
+        }
+      suma = sum_across_lane_groups(suma);
+      sumb = sum_across_lane_groups(sumb);
+      const float inva = __builtin_amdgcn_rcpf(suma), invb = __builtin_amdgcn_rcpf(sumb);
+
+      f32x4_t oa[4], ob[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { oa[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; ob[dt] = oa[dt]; }
+      constexpr int NC2 = NKT / 2;                       // 32-key chunks
+      constexpr int PCH = 4;                             // chunks per batch (the last batch may be shorter)
+#pragma unroll
+      for (int b0 = 0; b0 < NC2; b0 += PCH) {
+        constexpr int dummy = 0; (void)dummy;
+        const int nb = NC2 - b0 < PCH ? NC2 - b0 : PCH;  // compile-time after unrolling
+        s16x4_t t0[PCH][4], t1[PCH][4];
+#pragma unroll
+        for (int c = 0; c < PCH; ++c) {
+          if (c < nb) {
+            const char* vb = Vs + (b0 + c) * 32 * LDS_ROW + tr_off;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+              t0[c][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + dt * 32));
+              t1[c][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + 16 * LDS_ROW + dt * 32));
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < PCH; ++c) {
+          if (c < nb) {
+            const int cc = b0 + c;
+            const uint2 la = pack4<P>(sa[2 * cc][0], sa[2 * cc][1], sa[2 * cc][2], sa[2 * cc][3]);
+            const uint2 ha = pack4<P>(sa[2 * cc + 1][0], sa[2 * cc + 1][1], sa[2 * cc + 1][2], sa[2 * cc + 1][3]);
+            const uint2 lb = pack4<P>(sb[2 * cc][0], sb[2 * cc][1], sb[2 * cc][2], sb[2 * cc][3]);
+            const uint2 hb = pack4<P>(sb[2 * cc + 1][0], sb[2 * cc + 1][1], sb[2 * cc + 1][2], sb[2 * cc + 1][3]);
+            const s16x8_t pfa = __builtin_bit_cast(s16x8_t, make_uint4(la.x, la.y, ha.x, ha.y));
+            const s16x8_t pfb = __builtin_bit_cast(s16x8_t, make_uint4(lb.x, lb.y, hb.x, hb.y));
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+              const s16x8_t vf = __builtin_shufflevector(t0[c][dt], t1[c][dt], 0, 1, 2, 3, 4, 5, 6, 7);
+              oa[dt] = P::mfma(vf, pfa, oa[dt]);
+              ob[dt] = P::mfma(vf, pfb, ob[dt]);
+            }
+          }
+        }
+      }
+      const int Dm = p.heads * 64; (void)Dm;
+      if (qia < p.n_q) {
+        unsigned short* op = p.out + ((long)n * p.n_q + qia) * p.ldo + h * 64 + 4 * fg;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          *reinterpret_cast<uint2*>(op + dt * 16) = pack4<P>(oa[dt][0] * inva, oa[dt][1] * inva, oa[dt][2] * inva, oa[dt][3] * inva);
+      }
+      if (qib < p.n_q) {
+        unsigned short* op = p.out + ((long)n * p.n_q + qib) * p.ldo + h * 64 + 4 * fg;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          *reinterpret_cast<uint2*>(op + dt * 16) = pack4<P>(ob[dt][0] * invb, ob[dt][1] * invb, ob[dt][2] * invb, ob[dt][3] * invb);
+      }
+      q0 = na0; q1 = na1; qb0 = nb0; qb1 = nb1;
+    }
+  } else
   for (int qt = wave; qt < n_qt; qt += 4) {
     const int qi = qt * 16 + fr;
     // prefetch the next tile's Q while this one computes
@@ -222,9 +362,13 @@ template <class P>
 int launch_attn(const AttnParams& p, hipStream_t s) {
   dim3 grid(p.batch * p.heads), block(256);
   const int tiles = (p.n_keys + 15) / 16;
+  // two query tiles per wave for the big non-causal problems (vision blocks); GAVA_ATTN_PAIR=0 turns it off (A/B)
+  static const bool pair_ok = !(getenv("GAVA_ATTN_PAIR") && getenv("GAVA_ATTN_PAIR")[0] == '0');
+  const bool pair = pair_ok && !p.causal && !p.split && p.n_q >= 64;
 #define GAVA_ATTN(N)                                                                              \
   do {                                                                                            \
     if (p.causal) hipLaunchKernelGGL((attention_kernel<P, N, true>), grid, block, 0, s, p);       \
+    else if (pair && N >= 14) hipLaunchKernelGGL((attention_kernel<P, (N >= 14 ? N : 14), false, true>), grid, block, 0, s, p); \
     else hipLaunchKernelGGL((attention_kernel<P, N, false>), grid, block, 0, s, p);               \
   } while (0)
   if (tiles <= 2) GAVA_ATTN(2);
