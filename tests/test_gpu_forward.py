@@ -241,3 +241,22 @@ def test_layernorm_folding_on_and_off_both_meet_the_golden(golden_dir, cfg_name)
           f"{rel_to_max(out[False], g['logits']):.3e} folded-vs-plain {rel_to_max(out[True], out[False]):.3e}")
     assert rel_to_max(out[True], out[False]) < 1e-3
     assert not np.array_equal(out[True], out[False])   # the folded path really ran
+
+
+def test_layernorm_folding_vit_l14_three_blocks_vs_oracle():
+    """ViT-L/14 widths (D=1024: 16 row-sum slots, fc1 N=4096, qkv N=3072) with three blocks, so that norm1 of block 1 is
+    folded into its QKV GEMM as well (fed by block 0's fc2) - the two-block shape test above only reaches the norm2 fold."""
+    cfg = VitaConfig(num_frames=8, feature_dim=1024, patch_size=14, num_heads=16, num_layers=3, embed_dim=768,
+                     text_width=768, text_heads=12, text_layers=2)
+    m, sd = build(cfg)
+    assert m.fold_layernorm
+    x = torch.from_numpy(synth.synth_clip(2, cfg.num_frames, cfg.input_size, seed=5))
+    with torch.no_grad():
+        logits, _, _ = m(x.cuda())
+    assert bool(m._pack()["vis_layers"][1].w_qkv_fold)
+    o = Oracle(cfg, sd, torch.cat(m.tokenized_prompts)).forward(x, trace=True)
+    cls = m.last["cls_rows"].cpu().numpy()
+    per_layer = [rel_to_max(cls[i], o["trace"][f"block{i}"][:, 0].numpy()) for i in range(cfg.num_layers)]
+    e = rel_to_max(logits.cpu().numpy(), o["logits"].numpy())
+    print(f"\n[l14 x3, folded] logits rel-to-max {e:.3e}; cls rows per layer {['%.1e' % v for v in per_layer]}")
+    assert max(per_layer) < 3e-3 and e < 2e-3
