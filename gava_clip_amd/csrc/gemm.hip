@@ -410,7 +410,12 @@ void gemm256_kernel(const GemmParams p) {
   // indexed block behind the ring: no barrier is needed before it reads them back, only its own vmcnt.
   constexpr bool CAN_FOLD = FOLD;
   constexpr int FOLD_WAVE = 1280, FOLD_BYTES = NW * FOLD_WAVE;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (CAN_FOLD ? 2 * FOLD_BYTES : 0)];
+  // producers of the folding (EPI_F32 + x16_out): the 16-bit copy of a row group goes through a wave-private LDS block
+  // (16 rows x 128 B, 144-B pitch) so that it leaves as 128 contiguous bytes per row - 2 store instructions touching 16
+  // lines instead of 4 touching 64 (the 8-byte-per-lane stores were the whole +0.05 ms the producers paid)
+  constexpr bool X16_STAGE = EPI == GAVA_EPI_F32;
+  constexpr int XS_PITCH = 144, XS_WAVE = 16 * XS_PITCH;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (CAN_FOLD ? 2 * FOLD_BYTES : 0) + (X16_STAGE ? NW * XS_WAVE : 0)];
   constexpr bool fold = FOLD;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -738,14 +743,30 @@ void gemm256_kernel(const GemmParams p) {
             // producer side of the LayerNorm folding: 16-bit copy of the row segment + its (sum x, sum x^2)
             unsigned short* xo = p.x16 + orow * p.ldx16 + nb0;
             float ps1 = 0.f, ps2 = 0.f;
+            (void)xo;
+            if (X16_STAGE) {
+              char* xs = smem + 2 * STAGE + wave * XS_WAVE;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)   // natural column order: 8 bytes per lane, 32 contiguous bytes per row
-              *reinterpret_cast<uint2*>(xo + CJ * jj) = pack4<P>(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
+              for (int jj = 0; jj < 4; ++jj)
+                *reinterpret_cast<uint2*>(xs + fr * XS_PITCH + (CJ * jj + CF * fg) * 2) =
+                    pack4<P>(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) { ps1 += v[e]; ps2 += v[e] * v[e]; }
             ps1 = sum_across_lane_groups(ps1); ps2 = sum_across_lane_groups(ps2);
             if (fg == 0) p.rowsum[orow * (p.N / 64) + (n0 + wc * 64) / 64] = make_float2(ps1, ps2);
           }
+        }
+      }
+      if (X16_STAGE && p.x16 && !(p.ablate & 4)) {
+        // lane l: row (l >> 3) (+8 in the second pass), 16-byte chunk (l & 7) of the 128-byte row segment
+        const char* xs = smem + 2 * STAGE + wave * XS_WAVE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = (lane >> 3) + 8 * h;
+          const uint4 d = *reinterpret_cast<const uint4*>(xs + row * XS_PITCH + (lane & 7) * 16);
+          const int mm = m0 + wr * 128 + i * 16 + row;
+          if (mm < p.M) *reinterpret_cast<uint4*>(p.x16 + (long)mm * p.ldx16 + n0 + wc * 64 + (lane & 7) * 8) = d;
         }
       }
       // next tile: its residual rows go straight into the accumulators just freed (all 32 loads in flight
