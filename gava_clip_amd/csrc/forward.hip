@@ -41,6 +41,22 @@ int side_cus(bool ln1_folded) {
   return forced >= 0 ? forced : (ln1_folded ? 32 : 8);
 }
 
+// fc1 probe (gava_probe_fc1_enable / _read): event pairs around the roofline kernel inside the forward
+struct Fc1Probe {
+  hipEvent_t ev[64][2];
+  bool made = false, on = false;
+  int n = 0;
+  bool ensure() {
+    if (made) return true;
+    for (int i = 0; i < 64; ++i)
+      for (int k = 0; k < 2; ++k)
+        if (hipEventCreate(&ev[i][k]) != hipSuccess) return false;
+    made = true;
+    return true;
+  }
+};
+Fc1Probe g_probe;
+
 struct Carver {
   char* base; size_t off, cap;
   Carver(void* b, size_t c) : base((char*)b), off(0), cap(c) {}
@@ -142,6 +158,16 @@ int check_vision(const gava_vision_model* m) {
 
 extern "C" int gava_abi_version(void) { return 1; }
 
+extern "C" int gava_probe_fc1_enable(int on) { g_probe.on = on != 0; if (!on) g_probe.n = 0; return GAVA_OK; }
+extern "C" int gava_probe_fc1_read(float* ms, int cap) {
+  const int n = g_probe.n;
+  if (n <= 0 || !ms) return 0;
+  if (hipEventSynchronize(g_probe.ev[n - 1][1]) != hipSuccess) return 0;
+  for (int i = 0; i < n && i < cap; ++i)
+    if (hipEventElapsedTime(&ms[i], g_probe.ev[i][0], g_probe.ev[i][1]) != hipSuccess) return 0;
+  return n;
+}
+
 extern "C" size_t gava_vision_workspace_bytes(const gava_vision_model* m) {
   if (check_vision(m) != GAVA_OK) return 0;
   return carve_vision(m, nullptr, 0).total;
@@ -189,6 +215,8 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
 
   // ---- blocks (VitaCLIP_vision_encoder.py:115-121, VitaCLIP_vision_encoder_utils.py:155-203)
   bool folded_in = false;   // Xn / STATS already hold this block's un-normalised input and its row statistics
+  const bool probe = g_probe.on && m->layers <= 64 && g_probe.ensure();
+  if (probe) g_probe.n = 0;
   for (int i = 0; i < m->layers; ++i) {
     const gava_vision_layer& L = m->layer[i];
     TRY(keep(1 + i));
@@ -250,12 +278,17 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
         TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
         TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
         Fold c; c.stats = w.STATS; c.s = L.fc1_fold_s; c.t = L.fc1_fold_t;
+        if (probe && hipEventRecord(g_probe.ev[i][0], s) != hipSuccess) return GAVA_ELAUNCH;
         TRY(gemm(w.Xn, D, L.w_fc1_fold, D, nullptr, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, &c));
+        if (probe && hipEventRecord(g_probe.ev[i][1], s) != hipSuccess) return GAVA_ELAUNCH;
       } else {
         TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D));
         TRY(ln(w.X, D, nullptr, L.ln2_g, L.ln2_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
+        if (probe && hipEventRecord(g_probe.ev[i][0], s) != hipSuccess) return GAVA_ELAUNCH;
         TRY(gemm(w.Xn, D, L.w_fc1, D, L.b_fc1, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream));
+        if (probe && hipEventRecord(g_probe.ev[i][1], s) != hipSuccess) return GAVA_ELAUNCH;
       }
+      if (probe) g_probe.n = i + 1;
       if (fold1_next) {
         TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
         TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));

@@ -20,7 +20,8 @@ EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_vision_workspace_bytes", "gava_vision_forward", "gava_text_workspace_bytes",
            "gava_text_forward", "gava_similarity_head", "gava_convert_h16", "gava_debug_set_buffer",
            "gava_preprocess_clip", "gava_layernorm_backward", "gava_qgelu_backward", "gava_attention_backward",
-           "gava_text_forward_train", "gava_vision_forward_train", "gava_attention_backward_workspace_bytes", "gava_vision_forward_keep", "gava_row_stats"]
+           "gava_text_forward_train", "gava_vision_forward_train", "gava_attention_backward_workspace_bytes", "gava_vision_forward_keep", "gava_row_stats",
+           "gava_probe_fc1_enable", "gava_probe_fc1_read"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 
@@ -164,6 +165,8 @@ def load():
     lib.gava_attention_backward.restype = C.c_int
     lib.gava_attention_backward_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.gava_attention_backward_workspace_bytes.restype = C.c_size_t
+    lib.gava_probe_fc1_enable.argtypes = [C.c_int]
+    lib.gava_probe_fc1_read.argtypes = [C.POINTER(C.c_float), C.c_int]
     lib.gava_row_stats.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, _vp]
     lib.gava_row_stats.restype = C.c_int
     lib.gava_vision_forward_keep.argtypes = [C.POINTER(VisionModel), _fp, _fp, _fp, C.POINTER(VisionSaved), _vp, C.c_size_t, _vp]

@@ -46,6 +46,11 @@ int gava_abi_version(void);
 /* Debug hook: device buffer (u64[8] per wave) that instrumented kernels fill with per-segment cycle
  * sums; NULL (default) disables every stamp.  Not used by the product path. */
 int gava_debug_set_buffer(void* dev_u64);
+/* Measurement hook (bench.py `roofline`): while enabled, gava_vision_forward brackets the fc1 GEMM of every full-width
+ * block with a pair of HIP events on the stream it launches on.  gava_probe_fc1_read waits for the last pair and returns
+ * the number of pairs, writing up to `cap` elapsed times in ms.  Off by default; never enabled by the model code. */
+int gava_probe_fc1_enable(int on);
+int gava_probe_fc1_read(float* ms, int cap);
 
 /* C[M,N] = A[M,K] · W[N,K]^T with a fused epilogue.  Replaces nn.Linear / the conv-as-GEMM of
  * ImagePatchEmbed2D (VitaCLIP_vision_encoder_utils.py:66,79,110-115,215-219;
