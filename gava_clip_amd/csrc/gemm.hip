@@ -411,10 +411,11 @@ void gemm256_kernel(const GemmParams p) {
   constexpr bool CAN_FOLD = FOLD;
   constexpr int FOLD_WAVE = 1280, FOLD_BYTES = NW * FOLD_WAVE;
   // producers of the folding (EPI_F32 + x16_out): the 16-bit copy of a row group goes through a wave-private LDS block
-  // (16 rows x 128 B, 144-B pitch) so that it leaves as 128 contiguous bytes per row - 2 store instructions touching 16
-  // lines instead of 4 touching 64 (the 8-byte-per-lane stores were the whole +0.05 ms the producers paid)
+  // (16 rows x 128 B, 16-byte chunks XOR-swizzled by (row >> 1) & 7: conflict-free for the 8-byte writes and the 16-byte
+  // reads) so that it leaves as 128 contiguous bytes per row - 2 store instructions touching 16 lines instead of 4
+  // touching 64
   constexpr bool X16_STAGE = EPI == GAVA_EPI_F32;
-  constexpr int XS_PITCH = 144, XS_WAVE = 16 * XS_PITCH;
+  constexpr int XS_PITCH = 128, XS_WAVE = 16 * XS_PITCH;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (CAN_FOLD ? 2 * FOLD_BYTES : 0) + (X16_STAGE ? NW * XS_WAVE : 0)];
   constexpr bool fold = FOLD;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -748,7 +749,7 @@ void gemm256_kernel(const GemmParams p) {
               char* xs = smem + 2 * STAGE + wave * XS_WAVE;
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj)
-                *reinterpret_cast<uint2*>(xs + fr * XS_PITCH + (CJ * jj + CF * fg) * 2) =
+                *reinterpret_cast<uint2*>(xs + fr * XS_PITCH + (((2 * jj + (fg >> 1)) ^ ((fr >> 1) & 7)) << 4) + (fg & 1) * 8) =
                     pack4<P>(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
             }
 #pragma unroll
@@ -764,7 +765,7 @@ void gemm256_kernel(const GemmParams p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int row = (lane >> 3) + 8 * h;
-          const uint4 d = *reinterpret_cast<const uint4*>(xs + row * XS_PITCH + (lane & 7) * 16);
+          const uint4 d = *reinterpret_cast<const uint4*>(xs + row * XS_PITCH + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
           const int mm = m0 + wr * 128 + i * 16 + row;
           if (mm < p.M) *reinterpret_cast<uint4*>(p.x16 + (long)mm * p.ldx16 + n0 + wc * 64 + (lane & 7) * 8) = d;
         }
