@@ -1152,7 +1152,9 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   static const int variant = getenv("GAVA_GEMM_VARIANT") ? atoi(getenv("GAVA_GEMM_VARIANT")) : 0;
   // small-M problems (prompt path, text tower at few classes): 128x128 tiles fill more CUs;
   // the im2col-free patch loader lives in the templated kernel
-  if (gp.frames || gp.M <= 2048 || variant == 1) return launch_tile<P, 128, 128, 2>(gp, epi, s);
+  // im2col-free patch embedding: 128 x 256 tiles (8 waves) build every A tile for 3 instead of 6 N-tiles at D = 768
+  if (gp.frames && gp.N % 256 == 0 && variant != 1 && variant != 10) return launch_tile<P, 128, 256, 2>(gp, epi, s);
+  if (gp.frames || gp.M <= 2048 || variant == 1 || variant == 10) return launch_tile<P, 128, 128, 2>(gp, epi, s);
   if (variant == 2) return launch_tile<P, 256, 128, 3>(gp, epi, s);
   // measured at M = 100864 (c2): the persistent 256^2 kernel wins for N >= 1536 (qkv 0.42 vs 0.58 ms,
   // fc1 0.55 vs 0.78 ms) and, since the static wave priority, for the deep-K N = 768 GEMM (fc2 0.59 vs
