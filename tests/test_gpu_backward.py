@@ -440,3 +440,38 @@ def test_seventy_frame_clips_forward_and_backward_match_oracle():
         if r > 4e-2:
             bad[name] = r
     assert not bad, bad
+
+
+def test_full_size_backward_is_additive_over_the_batch():
+    """BASELINE config c2's training shape (64 clips, ViT-B/16): with a loss that is a sum over clips, the gradient of
+    the 64-clip batch equals the sum of the gradients of its two 32-clip halves (clips are independent, every trainable
+    parameter is shared) - a size-independent check of the full-size backward path (persistent dgrad GEMMs, MFMA
+    attention backward on 512 frames, kept activations).  bf16 gradient operands: norm-wise 2e-2."""
+    m = VitaCLIP(**model_kwargs(VIT_B16_T8, CLASSES_3))
+    m.load_state_dict(synth_torch_state(VIT_B16_T8, 3), strict=True)
+    m = m.cuda().train()
+    x = torch.from_numpy(synth.synth_clip(64, VIT_B16_T8.num_frames, VIT_B16_T8.input_size, seed=21)).cuda()
+    w = torch.randn(64, 3, generator=torch.Generator().manual_seed(4)).cuda()
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+
+    def grads(xs, ws):
+        for p in m.parameters():
+            p.grad = None
+        (m(xs)[0] * ws).sum().backward()
+        return {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    full = grads(x, w)
+    a, b = grads(x[:32], w[:32]), grads(x[32:], w[32:])
+    assert set(full) == set(names) == set(a) == set(b)
+    worst = ("", 0.0)
+    for n in names:
+        s = a[n] + b[n]
+        assert torch.isfinite(full[n]).all()
+        if float(s.norm()) < 1e-12:      # the exactly-zero key-bias gradient of the summary attention
+            assert float(full[n].norm()) < 1e-6
+            continue
+        e = rel(full[n], s)
+        if e > worst[1]:
+            worst = (n, e)
+    print(f"\n[c2 backward additivity] worst parameter {worst[0]}: {worst[1]:.3e}")
+    assert worst[1] < 2e-2, worst
