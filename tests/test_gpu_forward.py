@@ -284,3 +284,22 @@ def test_c2_full_size_batch_is_anchored_to_the_golden_and_deterministic(golden_d
     print(f"\n[c2 full size] rows 0-1 vs golden {e_gold:.3e}; vs the 2-clip batch {e_small:.3e}")
     assert e_gold < 1e-3
     assert e_small < 5e-4
+
+
+def test_c3_full_size_batch_is_anchored_to_the_oracle_and_deterministic():
+    """BASELINE config c3 (32 clips, 16 frames, 400 classes, full depth): the logits of clip 0 meet the oracle's for that
+    clip alone (clips are independent), two runs are bit-identical."""
+    from helpers import CLASSES_400
+    from gava_clip_amd.config import VIT_B16_T16
+    m, sd = build(VIT_B16_T16, class_file=CLASSES_400, n_cls=400)
+    m.debug_taps = False
+    x0 = torch.from_numpy(synth.synth_clip(1, 16, 224, seed=3))
+    x = torch.cat([x0, torch.from_numpy(synth.synth_clip(31, 16, 224, seed=77))]).cuda()
+    with torch.no_grad():
+        a = m(x)[0]
+        b = m(x)[0]
+    assert torch.equal(a, b) and tuple(a.shape) == (32, 400)
+    want = Oracle(VIT_B16_T16, sd, torch.cat(m.tokenized_prompts)).forward(x0)["logits"].numpy()
+    e = rel_to_max(a[:1].cpu().numpy(), want)
+    print(f"\n[c3 full size] clip 0 vs oracle {e:.3e}; argmax {int(a[0].argmax())} vs {int(want[0].argmax())}")
+    assert e < 1e-3
