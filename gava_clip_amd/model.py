@@ -750,8 +750,6 @@ class VitaCLIP(nn.Module):
         if train_vision:
             # differentiable vision tower (gava_clip_amd/training.py): gradients of the prompt parameters
             from .training import VisionTowerFn
-            if T != self.num_frames:
-                raise NotImplementedError("training needs T == num_frames (time_embed is resized otherwise)")
             cls_x, summary = VisionTowerFn.apply(self, x, *[p for _, p in self._vision_trainables()])
         else:
             cls_x, summary = self.encode_video(x)

@@ -239,6 +239,12 @@ def vision_backward(model, saved, dcls_x, B, T, dsummary=None, kept=None):
     bw = model._pack_vision_backward()
     D, H, F, E, G, NL = sh["D"], sh["H"], sh["F"], sh["E"], sh["G"], sh["layers"]
     n1 = (sh["size"] // sh["P"]) ** 2 + 1
+    # T_in frames per input clip; the blocks regroup the B*T_in frames by the MODEL's num_frames regardless
+    # (vision_encoder_utils.py:160-162): inside the block loop (B, T) are (groups, num_frames), the head and the temporal
+    # embedding keep the input's (B_in, T_in)
+    B_in, T_in = B, T
+    T = model.num_frames
+    B = B_in * T_in // T
     BT, R, SR = B * T, B * T * n1, G + 2 * B * T
     dev = dcls_x.device
     bf = torch.bfloat16
@@ -249,7 +255,7 @@ def vision_backward(model, saved, dcls_x, B, T, dsummary=None, kept=None):
     cls_idx = (torch.arange(BT, device=dev, dtype=torch.int32) * n1).contiguous()
 
     # ---- head: cls_x = mean_t(ln_post(x_cls) @ proj)                          (VitaCLIP_vision_encoder.py:126-128)
-    dproj = (dcls_x.float() / T).unsqueeze(1).expand(B, T, E).reshape(BT, E).contiguous()
+    dproj = (dcls_x.float() / T_in).unsqueeze(1).expand(B_in, T_in, E).reshape(BT, E).contiguous()
     dclspost = new(BT, D, dtype=torch.float32)
     hip.gemm(hip.convert_h16(dproj, BWD), bw["proj"], None, dclspost, epilogue=hip.EPI_F32, prec=BWD)
     dX = torch.zeros(R, D, dtype=torch.float32, device=dev)
@@ -386,7 +392,11 @@ def vision_backward(model, saved, dcls_x, B, T, dsummary=None, kept=None):
     # ---- ln_pre' and the temporal embedding (VitaCLIP_vision_encoder.py:86-100,108-113): time_embed[t] is added to
     #      every token of frame t
     hip.layernorm_backward(kept["e0"] if kept is not None else saved[0], v.ln_pre.weight.detach().float().contiguous(), dX, dX)
-    grads["time_embed"] = dX.view(B, T, n1, D).sum(dim=(0, 2))
+    dte = dX.view(B_in, T_in, n1, D).sum(dim=(0, 2))
+    if T_in != T:   # nearest-resized time_embed (VitaCLIP_vision_encoder.py:91-95): row t of the resized table is row floor(t*T/T_in)
+        src = (torch.arange(T_in, device=dev) * T) // T_in
+        dte = torch.zeros(T, D, dtype=dte.dtype, device=dev).index_add_(0, src, dte)
+    grads["time_embed"] = dte
     return grads
 
 

@@ -475,3 +475,32 @@ def test_full_size_backward_is_additive_over_the_batch():
             worst = (n, e)
     print(f"\n[c2 backward additivity] worst parameter {worst[0]}: {worst[1]:.3e}")
     assert worst[1] < 2e-2, worst
+
+
+@pytest.mark.parametrize("keep", [True, False])
+def test_training_with_more_frames_than_num_frames_matches_oracle_autograd(keep):
+    """T_in = 2 * num_frames under autograd: frames are regrouped by the model's num_frames (utils:160-162) and the
+    temporal embedding is nearest-resized (vision_encoder.py:91-95), so d time_embed gathers two input frames per row."""
+    cfg, B = TINY, 2
+    sd = synth_torch_state(cfg, 3)
+    m = VitaCLIP(**model_kwargs(cfg, CLASSES_3))
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    if not keep:
+        m.keep_activation_bytes = 0
+    x = torch.from_numpy(synth.synth_clip(B, 2 * cfg.num_frames, cfg.input_size, seed=13))
+    wlog = torch.randn(B, 3, generator=torch.Generator().manual_seed(6))
+    ref_logits, ref = _oracle_all_grads(cfg, sd, torch.cat(m.tokenized_prompts).cpu(), x, wlog)
+    logits = m(x.cuda())[0]
+    (logits * wlog.cuda()).sum().backward()
+    assert (logits.detach().cpu() - ref_logits).abs().max() <= 1e-3 * ref_logits.abs().max()
+    got = {n: p.grad for n, p in m.named_parameters()}
+    bad = {}
+    for name, g_ref in ref.items():
+        if name.endswith("k_proj.bias"):
+            continue
+        e = rel(got[name].cpu(), g_ref)
+        if e > 4e-2:
+            bad[name] = e
+    assert not bad, bad
+    assert got["visual.time_embed"].shape == (cfg.num_frames, cfg.feature_dim)
