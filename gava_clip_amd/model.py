@@ -170,8 +170,10 @@ class ContextualPromptLearner(nn.Module):
     def __init__(self, use_cntn, cntn_split, uni_mlp, use_disc, emb_dim, out_dim, inp_dim=768, n_cls=4, n_tokens=16,
                  cls_type="updrs", knowledge_version=("v0",), use_descriptor=False, token_wise_mlp=False):
         super().__init__()
-        if use_descriptor or token_wise_mlp:
-            raise NotImplementedError("KAPT: use_descriptor / token_wise_mlp variants are not built")
+        if token_wise_mlp:   # upstream: asserts against class_wise_mlp=True (kapt_head.py:63) and reads an unbound idc (:201)
+            raise NotImplementedError("KAPT: token_wise_mlp=True does not run in the reference")
+        if use_descriptor:
+            raise NotImplementedError("KAPT: use_descriptor=True (ragged per-class descriptors, kapt_head.py:65-88) is not built")
         if not (use_cntn and cntn_split and uni_mlp):
             # upstream: without `split` ke_v0_path is read before assignment (kapt_head.py:91), without `uni` a Python
             # list is .expand()-ed (:187-191), without `cntn` a 2-D ctx is concatenated with 3-D prefixes (text_encoder.py:325)
