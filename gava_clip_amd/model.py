@@ -413,6 +413,7 @@ class VitaCLIP(nn.Module):
         self._text_stream = None
         self._text_cache = None
         self.gather_across_ranks = True     # RCCL all-gather of clip embeddings when world_size > 1
+        self.shard_text_across_ranks = True  # eval, world_size > 1: each rank encodes a slice of the prompts (+ all-gather)
         self.debug_taps = False             # keep per-layer CLS rows of the last forward
         self._shape = dict(size=input_size[0], P=patch_size[0], D=feature_dim, H=num_heads, layers=num_layers,
                            F=round(mlp_factor * feature_dim), E=embed_dim, G=num_global_prompts,
@@ -634,11 +635,41 @@ class VitaCLIP(nn.Module):
         self.last["cls_rows"] = dbg
         return cls_x, summary
 
+    def _text_shard(self, n):
+        """(lo, hi, rows per rank, world) when the prompts are sharded over the ranks, else None (SURVEY.md 8f row 2:
+        every rank would otherwise run the whole text tower redundantly - 2.4 TF per forward at 400 classes)."""
+        import torch.distributed as dist
+        if not (self.shard_text_across_ranks and self.gather_across_ranks and not torch.is_grad_enabled()
+                and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return None
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if n < 2 * world:
+            return None
+        per = (n + world - 1) // world
+        return min(n, rank * per), min(n, (rank + 1) * per), per, world
+
     def encode_text(self):
-        """prompt_learner() + textual(...) for all classes in one batch -> (C, E) fp32."""
+        """prompt_learner() + textual(...) for all classes in one batch -> (C, E) fp32.  With several ranks (eval) each
+        rank encodes a contiguous slice of the prompts and the rows are all-gathered: prompts are independent, so the
+        result is the same as every rank encoding all of them."""
+        pk, sh = self._pack(), self._shape
+        n = pk["tokens"].shape[0]
+        shard = self._text_shard(n)
+        if shard is None:
+            return self._encode_text_rows(0, n)
+        lo, hi, per, world = shard
+        part = torch.zeros(per, sh["E"], dtype=torch.float32, device=pk["tokens"].device)
+        if hi > lo:
+            part[:hi - lo] = self._encode_text_rows(lo, hi)
+        # rank r holds prompts [r*per, (r+1)*per): the rank-major concatenation is already in prompt order, padding last
+        return self._gather(part)[:n].contiguous()
+
+    def _encode_text_rows(self, lo, hi):
+        """The text tower on prompts [lo, hi)."""
         lib = hip.load()
         pk, sh = self._pack(), self._shape
-        tok = pk["tokens"]
+        L = self.text_rows_per_prompt
+        tok = pk["tokens"][lo:hi].contiguous()
         n = tok.shape[0]
         m = hip.TextModel()
         m.n_prompts, m.L, m.W, m.H, m.layers = n, self.text_rows_per_prompt, sh["W"], sh["TH"], sh["TL"]
@@ -651,9 +682,10 @@ class VitaCLIP(nn.Module):
         if nbytes == 0:
             raise hip.GavaError(f"unsupported text shape: {sh}")
         ws = self._workspace("text", nbytes, tok.device)
-        ctx = self.prompt_learner.full_context().detach().float().contiguous()
+        ctx = self.prompt_learner.full_context().detach().float()[lo:hi].contiguous()
+        eot = (pk["eot"][lo:hi] - lo * L).to(torch.int32).contiguous()      # flat row index n*L + column, rebased to the slice
         out = torch.empty(n, sh["E"], dtype=torch.float32, device=tok.device)
-        hip.check(lib.gava_text_forward(C.byref(m), hip.ptr(tok), hip.ptr(ctx), hip.ptr(pk["eot"]), hip.ptr(out),
+        hip.check(lib.gava_text_forward(C.byref(m), hip.ptr(tok), hip.ptr(ctx), hip.ptr(eot), hip.ptr(out),
                                         hip.ptr(ws), ws.numel(), hip.stream_ptr()), "gava_text_forward")
         return out
 

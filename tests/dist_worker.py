@@ -59,6 +59,37 @@ def sharded_forward_gpu(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def sharded_text_gpu(rank, world, port, out_dir):
+    """400 classes: each rank encodes 200 prompts and the rows are all-gathered; features and logits
+    must equal the single-process ones."""
+    from gava_clip_amd import VitaCLIP, synth
+    from gava_clip_amd.config import VitaConfig
+    from helpers import CLASSES_400, model_kwargs, synth_torch_state
+    _init(rank, world, port)
+    torch.set_num_threads(2)
+    cfg = VitaConfig(input_size=64, num_frames=4, feature_dim=128, num_heads=2, num_layers=1, embed_dim=512,
+                     num_global_prompts=4, text_layers=2)
+    m = VitaCLIP(**model_kwargs(cfg, CLASSES_400))
+    m.load_state_dict(synth_torch_state(cfg, 400), strict=True)
+    m = m.cuda().eval()
+    b = 1
+    x = torch.from_numpy(synth.synth_clip(b * world, cfg.num_frames, cfg.input_size)).cuda()
+    with torch.no_grad():
+        assert m._text_shard(400) is not None
+        logits, _, _ = m(x[rank * b:(rank + 1) * b])
+        tf = m.text_features.clone()
+        m.gather_across_ranks = False
+        assert m._text_shard(400) is None
+        full, _, _ = m(x)
+        tf_full = m.text_features.clone()
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"tsharded{rank}.npy"), logits.cpu().numpy())
+    np.save(os.path.join(out_dir, f"tfull{rank}.npy"), full.cpu().numpy())
+    np.save(os.path.join(out_dir, f"tf{rank}.npy"), np.stack([tf.cpu().numpy(), tf_full.cpu().numpy()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def ddp_train_gpu(rank, world, port, out_dir):
     """DistributedDataParallel around the drop-in model as training/train.py:347 does: each rank backpropagates its
     own clips through the HIP backward, DDP averages the gradients (gloo here; RCCL on a multi-GPU node).  The
@@ -100,4 +131,5 @@ def ddp_train_gpu(rank, world, port, out_dir):
 
 if __name__ == "__main__":
     fn, rank, world, port, out_dir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-    {"gather_cpu": gather_cpu, "sharded_forward_gpu": sharded_forward_gpu, "ddp_train_gpu": ddp_train_gpu}[fn](rank, world, port, out_dir)
+    {"gather_cpu": gather_cpu, "sharded_forward_gpu": sharded_forward_gpu, "ddp_train_gpu": ddp_train_gpu,
+     "sharded_text_gpu": sharded_text_gpu}[fn](rank, world, port, out_dir)

@@ -57,3 +57,16 @@ def test_ddp_gradients_equal_single_process(tmp_path):
     for r in range(2):
         worst, n = np.load(tmp_path / f"ddp{r}.npy")
         assert n > 20 and worst <= 2e-2, (worst, n)
+
+
+@pytest.mark.gpu
+def test_text_tower_sharded_over_ranks_equals_single_process(tmp_path):
+    """2 ranks sharing cuda:0, 400 classes: each rank encodes half of the prompts, the rows are all-gathered; class
+    features and logits equal the unsharded ones (prompts are independent; the GEMMs see a different M, so allow the
+    last bit)."""
+    _run("sharded_text_gpu", 2, tmp_path, timeout=600)
+    full = np.load(tmp_path / "tfull0.npy")
+    for r in range(2):
+        tf = np.load(tmp_path / f"tf{r}.npy")
+        assert np.abs(tf[0] - tf[1]).max() <= 1e-6
+        assert np.abs(np.load(tmp_path / f"tsharded{r}.npy") - full).max() <= 1e-5 * np.abs(full).max()
