@@ -172,19 +172,30 @@ class ContextualPromptLearner(nn.Module):
         super().__init__()
         if token_wise_mlp:   # upstream: asserts against class_wise_mlp=True (kapt_head.py:63) and reads an unbound idc (:201)
             raise NotImplementedError("KAPT: token_wise_mlp=True does not run in the reference")
-        if use_descriptor:
-            raise NotImplementedError("KAPT: use_descriptor=True (ragged per-class descriptors, kapt_head.py:65-88) is not built")
         if not (use_cntn and cntn_split and uni_mlp):
             # upstream: without `split` ke_v0_path is read before assignment (kapt_head.py:91), without `uni` a Python
             # list is .expand()-ed (:187-191), without `cntn` a 2-D ctx is concatenated with 3-D prefixes (text_encoder.py:325)
             raise NotImplementedError("KAPT: only text_prompt_init with cntn+split+uni (optionally disc) runs in the reference")
-        assert len(knowledge_version) > 0, "No knowledge is specified."
+        assert len(knowledge_version) > 0 or use_descriptor, "No knowledge is specified."
         self.type = cls_type.lower().split("_")[0]
         self.n_cls, self.n_tokens = n_cls, n_tokens
+        self.use_descriptor = use_descriptor
         self.updrs_ke_dir = f"./data/ke_{self.type}"
         assert os.path.isdir(self.updrs_ke_dir), f"{self.updrs_ke_dir} (KEPLER knowledge files) not found"
         embeds = torch.empty(n_cls, 0, inp_dim)
         cls_disc = [[] for _ in range(n_cls)]
+        if use_descriptor:
+            # per-class descriptors instead of one description per knowledge version (kapt_head.py:65-88): class c has as
+            # many prompts as descriptor_<c>.txt has lines, each with its own entity embedding (descriptor_<c>.npy)
+            np.load(os.path.join(self.updrs_ke_dir, "all.npy"), allow_pickle=False)     # read upstream as well (:68)
+            embeds = []
+            for idc in range(n_cls):
+                with open(os.path.join(self.updrs_ke_dir, f"descriptor_{idc}.txt")) as f:
+                    cls_disc[idc] = [ln.strip() for ln in f]
+                ent = np.load(os.path.join(self.updrs_ke_dir, f"descriptor_{idc}.npy"), allow_pickle=False)
+                assert ent.shape[0] == len(cls_disc[idc])
+                embeds.append(torch.from_numpy(ent).float())
+            knowledge_version = ()
         for kv in knowledge_version:
             ent = np.load(os.path.join(self.updrs_ke_dir, f"EntityEmb_{kv}.npy"), allow_pickle=False)[:n_cls]
             embeds = torch.cat([embeds, torch.from_numpy(ent).float().unsqueeze(1)], dim=1)
@@ -235,8 +246,11 @@ class TextPromptLearner(_Params):
                 emb_dim=ctx_dim // 4, out_dim=ctx_dim, n_cls=n_cls, n_tokens=n_ctx, cls_type=cls_type,
                 knowledge_version=list(knowledge_version), use_descriptor=use_descriptor, token_wise_mlp=token_wise_mlp)
             self.ctx = nn.Parameter(torch.zeros(n_cls, n_ctx, ctx_dim))                      # :218-220
-            texts = [[self.context_prompt_learner.cls_disc[c][k] + " " + names[c] for k in range(len(knowledge_version))]
-                     for c in range(n_cls)]                                                  # :256-258
+            if use_descriptor:                                                               # :253-255
+                texts = [[d + " " + names[c] for d in self.context_prompt_learner.cls_disc[c]] for c in range(n_cls)]
+            else:
+                texts = [[self.context_prompt_learner.cls_disc[c][k] + " " + names[c] for k in range(len(knowledge_version))]
+                         for c in range(n_cls)]                                              # :256-258
         else:
             if not CSC:
                 # upstream: a generic (n_ctx, dim) ctx is unsqueezed to (n_ctx,1,dim) and cannot be
@@ -252,8 +266,9 @@ class TextPromptLearner(_Params):
         assert max(int((tp == 49407).nonzero()[:, -1].max()) for tp in self.tokenized_prompts) <= 77, \
             "The tokenized prompt is too long"
         self.n_cls, self.n_ctx = n_cls, n_ctx
-        self.n_kv = self.tokenized_prompts[0].shape[0]
-        assert all(tp.shape[0] == self.n_kv for tp in self.tokenized_prompts)
+        # prompts per class: uniform (n_kv knowledge versions) or ragged (use_descriptor); n_kv is None when ragged
+        self.kv_counts = [int(tp.shape[0]) for tp in self.tokenized_prompts]
+        self.n_kv = self.kv_counts[0] if len(set(self.kv_counts)) == 1 else None
         self.class_token_position = ctx_pos
 
     def embedding_token_ids(self):
@@ -706,6 +721,16 @@ class VitaCLIP(nn.Module):
         dist.all_gather_into_tensor(out, feats)
         return out
 
+    def _class_mean_matrix(self, device):
+        """(n_prompts, n_cls) matrix with 1/count_c in the rows of class c's prompts: flat logits @ A = per-class means."""
+        counts = self.prompt_learner.kv_counts
+        A = torch.zeros(sum(counts), len(counts), dtype=torch.float32, device=device)
+        r = 0
+        for c, k in enumerate(counts):
+            A[r:r + k, c] = 1.0 / k
+            r += k
+        return A
+
     def _vision_trainables(self):
         from .training import _vision_trainables
         return _vision_trainables(self)
@@ -718,7 +743,10 @@ class VitaCLIP(nn.Module):
         tf = text / text.norm(dim=-1, keepdim=True)
         logits = self.logit_scale.exp() * vf @ tf.t()
         n_kv = self.prompt_learner.n_kv if self.use_text_prompt_learning else 1
-        if n_kv > 1:                                   # VitaCLIP_model.py:288-290
+        if n_kv is None:                               # ragged (use_descriptor): per-class means by an averaging matrix
+            A = self._class_mean_matrix(tf.device)
+            logits, tf = logits @ A, A.t() @ tf
+        elif n_kv > 1:                                 # VitaCLIP_model.py:288-290
             logits = logits.view(logits.shape[0], -1, n_kv).mean(-1)
             tf = tf.view(-1, n_kv, tf.shape[-1]).mean(1)
         if self.logit_bias is not None:
@@ -798,7 +826,8 @@ class VitaCLIP(nn.Module):
         else:
             Bg, Cn = video.shape[0], text.shape[0]
             n_kv = self.prompt_learner.n_kv if self.use_text_prompt_learning else 1
-            if desc_wise and self.use_text_prompt_learning:
+            ragged = n_kv is None        # use_descriptor: the head runs per prompt, the (tiny) class means follow in torch
+            if (desc_wise and self.use_text_prompt_learning) or ragged:
                 n_cls, n_kv = Cn, 1      # per-description logits (VitaCLIP_model.py:265-276): every prompt is its own "class"
             else:
                 n_cls = Cn // n_kv
@@ -811,11 +840,16 @@ class VitaCLIP(nn.Module):
                                                sh["E"], hip.ptr(logits), hip.ptr(tfeat), hip.ptr(vnorm), hip.stream_ptr()),
                       "gava_similarity_head")
             self.last.update(video_features=vnorm, summary=summary)
-            if self.use_text_prompt_learning:
-                self.text_features = tfeat            # VitaCLIP_model.py:293
             if desc_wise and self.use_text_prompt_learning:
-                k = self.prompt_learner.n_kv
-                logits = [logits[:, i:i + k] for i in range(0, Cn, k)]   # list of (B, n_kv)
+                self.text_features = tfeat            # upstream leaves the last class's features here; not relied upon
+                logits = list(torch.split(logits, self.prompt_learner.kv_counts, dim=1))     # list of (B, n_kv_c)
+            elif ragged:
+                A = self._class_mean_matrix(x.device)                                        # VitaCLIP_model.py:288-291
+                logits = logits @ A      # (a logit_bias, added per prompt by the head, survives the mean unchanged)
+                tf = A.t() @ tfeat
+                self.text_features = tf / tf.norm(dim=-1, keepdim=True)
+            elif self.use_text_prompt_learning:
+                self.text_features = tfeat            # VitaCLIP_model.py:293
 
         # auxiliary heads: inactive at every accelerated configuration; kept as PyTorch glue on the device so that
         # callers passing video_nte / memory still get the reference's outputs - and, in training, its gradients

@@ -181,6 +181,26 @@ def synth_knowledge_files(root: str, cls_type: str, n_cls: int, versions, seed: 
     return d
 
 
+KAPT_DESCRIPTORS = ("arms swing {} while walking", "{} shuffling of the feet", "the trunk is {} bent forward",
+                    "turning takes {} many steps", "{} freezing at the start")
+
+
+def synth_descriptor_files(root: str, cls_type: str, counts, seed: int = 0, inp_dim: int = 768):
+    """Synthetic per-class descriptor files for KAPT's use_descriptor mode (kapt_head.py:65-88): all.npy (n_cls, 768),
+    descriptor_<c>.txt (counts[c] lines) and descriptor_<c>.npy (counts[c], 768).  A ragged number of prompts per class."""
+    import os
+    d = os.path.join(root, "data", "ke_" + cls_type.lower().split("_")[0])
+    os.makedirs(d, exist_ok=True)
+    levels = ("no", "slight", "mild", "moderate", "severe", "very severe")
+    np.save(os.path.join(d, "all.npy"), normalish("kapt.entity.all", (len(counts), inp_dim), seed).astype(np.float32))
+    for c, k in enumerate(counts):
+        np.save(os.path.join(d, f"descriptor_{c}.npy"), normalish(f"kapt.descriptor.{c}", (k, inp_dim), seed).astype(np.float32))
+        with open(os.path.join(d, f"descriptor_{c}.txt"), "w") as f:
+            for j in range(k):
+                f.write(KAPT_DESCRIPTORS[(c + j) % len(KAPT_DESCRIPTORS)].format(levels[c % len(levels)]) + "\n")
+    return d
+
+
 def synth_kapt_state(cfg: VitaConfig, n_cls: int, seed: int = 0, inp_dim: int = 768):
     from collections import OrderedDict
     W = cfg.text_width

@@ -504,3 +504,34 @@ def test_training_with_more_frames_than_num_frames_matches_oracle_autograd(keep)
             bad[name] = e
     assert not bad, bad
     assert got["visual.time_embed"].shape == (cfg.num_frames, cfg.feature_dim)
+
+
+def test_kapt_descriptor_mode_forward_and_gradients_match_reference(golden_dir, tmp_path, monkeypatch):
+    """KAPT with use_descriptor=True: a ragged number of prompts per class (2, 3, 1 descriptors).  Eval logits (mean over
+    each class's own prompts), class features, the per-descriptor logits and every train-mode gradient against the
+    fixture the reference produced on the same synthetic descriptor files."""
+    import numpy as np, os
+    gold = np.load(os.path.join(golden_dir, "tiny_kapt_desc.npz"))
+    synth.synth_descriptor_files(str(tmp_path), "updrs", (2, 3, 1))
+    monkeypatch.chdir(tmp_path)
+    m = VitaCLIP(**{**model_kwargs(TINY, CLASSES_3), "text_prompt_init": "cntn_split_uni_disc", "knowledge_version": ["v1", "v2", "v3"],
+                    "use_descriptor": True})
+    sd = synth_torch_state(TINY, 3)
+    sd.update({k: torch.from_numpy(v) for k, v in synth.synth_kapt_state(TINY, 3).items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    x = torch.from_numpy(synth.synth_clip(2, TINY.num_frames, TINY.input_size)).cuda()
+    with torch.no_grad():
+        logits = m(x)[0]
+        tfeat = m.text_features.clone()
+        desc = m(x, desc_wise=True)[0]
+    assert [tuple(d.shape) for d in desc] == [(2, 2), (2, 3), (2, 1)]
+    for got, key in ((logits, "logits"), (tfeat, "text_features"), (torch.cat(desc, 1), "desc_logits")):
+        ref = torch.from_numpy(gold[key])
+        assert got.shape == ref.shape, key
+        assert (got.cpu() - ref).abs().max() <= 1e-3 * ref.abs().max(), key
+    m.train()
+    lg = m(x)[0]
+    (lg * torch.from_numpy(gold["w_logits"]).cuda()).sum().backward()
+    worst = _check_against_reference_grads(m, gold)
+    assert any("context_prompt_learner.projector" in k for k in worst)

@@ -119,3 +119,26 @@ def test_flop_model_matches_survey():
     assert abs(text_flops_per_prompt(VIT_B16_T8) / 1e9 - 5.9595) < 0.001
     assert abs(forward_flops(VIT_B16_T8, 64, 3) / 1e9 - 19127.8) < 0.5
     assert abs(vision_flops_per_clip(VIT_L14_T32) / 1e9 - 5631.77) < 0.1
+
+
+def test_kapt_descriptor_prompts_are_ragged_like_the_reference(golden_dir, tmp_path, monkeypatch):
+    """KAPT with use_descriptor=True (kapt_head.py:65-88): class c gets one prompt per line of descriptor_<c>.txt -
+    2, 3 and 1 prompts here; token ids equal the reference's, context rows are ctx[c] + MLP_c(descriptor embedding)."""
+    import os
+    import torch
+    from gava_clip_amd import VitaCLIP, synth
+    g = np.load(os.path.join(golden_dir, "tiny_kapt_desc.npz"))
+    synth.synth_descriptor_files(str(tmp_path), "updrs", (2, 3, 1))
+    monkeypatch.chdir(tmp_path)
+    m = VitaCLIP(**{**model_kwargs(TINY), "text_prompt_init": "cntn_split_uni_disc", "knowledge_version": ["v1", "v2", "v3"],
+                    "use_descriptor": True})
+    pl = m.prompt_learner
+    assert pl.kv_counts == [2, 3, 1] and pl.n_kv is None
+    assert np.array_equal(torch.cat(m.tokenized_prompts).numpy(), g["tokens"])
+    assert [k for k in m.state_dict() if "context_prompt_learner" in k] == list(synth.synth_kapt_state(TINY, 3).keys())
+    full = pl.full_context()
+    assert full.shape == (6, TINY.text_num_prompts, TINY.text_width)
+    A = m._class_mean_matrix(torch.device("cpu"))
+    assert A.shape == (6, 3) and torch.allclose(A.sum(0), torch.ones(3)) and float(A[2:5, 1].min()) == pytest.approx(1 / 3)
+    with pytest.raises(NotImplementedError):
+        VitaCLIP(**{**model_kwargs(TINY), "text_prompt_init": "cntn_split_uni_disc", "token_wise_mlp": True})

@@ -175,7 +175,10 @@ def run_grad_case(mod, cfg, class_file, B, name, aux, sampled=False):
 KAPT_VERSIONS = ["v1", "v2", "v3"]
 
 
-def run_kapt_case(mod, cfg, class_file, B, name):
+KAPT_DESC_COUNTS = (2, 3, 1)
+
+
+def run_kapt_case(mod, cfg, class_file, B, name, descriptors=False):
     """Knowledge-aware prompts (training/kapt_head.py, text_prompt_init='cntn_split_uni_disc', the configuration of
     train_scripts/updrs_3cls_train_tulip.sh) on SYNTHETIC knowledge files (the real ./data/ke_* are not distributed):
     eval logits / text features / per-description logits, and train-mode gradients incl. the context MLPs."""
@@ -184,11 +187,14 @@ def run_kapt_case(mod, cfg, class_file, B, name):
     n_cls = len(read_class_names(class_file))
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:
-        synth.synth_knowledge_files(tmp, "updrs", n_cls, KAPT_VERSIONS)
+        if descriptors:   # use_descriptor=True: a ragged number of prompts per class (kapt_head.py:65-88)
+            synth.synth_descriptor_files(tmp, "updrs", KAPT_DESC_COUNTS)
+        else:
+            synth.synth_knowledge_files(tmp, "updrs", n_cls, KAPT_VERSIONS)
         os.chdir(tmp)
         try:
             model = build_reference(mod, cfg, class_file, text_prompt_init="cntn_split_uni_disc",
-                                    knowledge_version=list(KAPT_VERSIONS), cls_type="updrs")
+                                    knowledge_version=list(KAPT_VERSIONS), cls_type="updrs", use_descriptor=descriptors)
         finally:
             os.chdir(cwd)
     load_synth(model, cfg, n_cls, kapt=True)
@@ -199,7 +205,8 @@ def run_kapt_case(mod, cfg, class_file, B, name):
         logits, _, _ = model(x)
         tfeat = model.text_features.clone()
         desc, _, _ = model(x, desc_wise=True)
-    out = dict(logits=logits.numpy(), text_features=tfeat.numpy(), desc_logits=np.stack([d.numpy() for d in desc]),
+    out = dict(logits=logits.numpy(), text_features=tfeat.numpy(),
+               desc_logits=(np.concatenate([d.numpy() for d in desc], 1) if descriptors else np.stack([d.numpy() for d in desc])),
                tokens=torch.cat(model.tokenized_prompts).numpy().astype(np.int32))
     model.train()
     w1 = torch.randn(B, n_cls, generator=torch.Generator().manual_seed(2024))
@@ -240,3 +247,4 @@ if __name__ == "__main__":
     run_grad_case(mod, TINY, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "tiny_aux_grads", True)
     run_grad_case(mod, VIT_B16_T8, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 1, "b16_grads", False, sampled=True)
     run_kapt_case(mod, TINY, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "tiny_kapt")
+    run_kapt_case(mod, TINY, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "tiny_kapt_desc", descriptors=True)
