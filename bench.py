@@ -283,14 +283,19 @@ def main():
             import ctypes as C_
             from gava_clip_amd import hip as hip_
             lib_ = hip_.load()
+            gather_was = model.gather_across_ranks
+            model.gather_across_ranks = False      # rank 0 runs these forwards alone: no collective may be entered
             lib_.gava_probe_fc1_enable(1)
             samples = []
-            for _ in range(5):
-                step()
-                buf = (C_.c_float * 64)()
-                n_ = lib_.gava_probe_fc1_read(buf, 64)
-                samples += [buf[i] for i in range(n_)]
-            lib_.gava_probe_fc1_enable(0)
+            try:
+                for _ in range(5):
+                    step()
+                    buf = (C_.c_float * 64)()
+                    n_ = lib_.gava_probe_fc1_read(buf, 64)
+                    samples += [buf[i] for i in range(n_)]
+            finally:
+                lib_.gava_probe_fc1_enable(0)
+                model.gather_across_ranks = gather_was
             if samples:
                 in_fwd = sum(samples) / len(samples)
         except Exception as e:   # the probe must never break the bench line
