@@ -34,6 +34,15 @@ def log(msg):
         print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def kernel_source_hash():
+    """sha256 over the GEMM kernel sources the roofline kernel is built from (recorded by tools/make_traffic.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "common.h"):
+        h.update(open(os.path.join(REPO, "gava_clip_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def host_cores():
     try:
         n = len(os.sched_getaffinity(0))
@@ -48,6 +57,7 @@ CONFIGS = {
     # name: (VitaConfig name, clips per GPU, class file, description)
     "c2": ("VIT_B16_T8", 64, "updrs_3cls_classes.txt", "ViT-B/16, 8 frames, 224^2, batch 64/GPU, 3 classes"),
     "c3": ("VIT_B16_T16", 32, "k400_classes.txt", "ViT-B/16, 16 frames, 224^2, batch 32/GPU, 400 classes"),
+    "c5": ("VIT_L14_T32", 32, "updrs_3cls_classes.txt", "ViT-L/14, 32 frames, 224^2, batch 32/GPU, 3 classes"),
     "c1": ("VIT_B16_T8", 2, "updrs_3cls_classes.txt", "ViT-B/16, 8 frames, 224^2, batch 2, 3 classes"),
 }
 
@@ -55,14 +65,15 @@ CONFIGS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)     # SURVEY 8d protocol: >= 10 warm-up + >= 50 timed forwards
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--prec", default=os.environ.get("GAVA_PREC", "fp16"), choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the stand-alone kernel timings")
     ap.add_argument("--no-alt", action="store_true", help="skip the short run in the other operand dtype")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the logits-vs-reference-golden check")
     return ap.parse_args()
 
 
@@ -177,6 +188,32 @@ def kernel_table(cfg, B, prec, fold=False):
     return rows
 
 
+def accuracy_vs_golden(model, cfg, prec):
+    """BASELINE.json's third metric, "logits max-abs-err vs ref": the model is re-loaded with the synthetic weights the
+    REFERENCE produced tests/golden/c1_b16.npz from (config c1 = the first two clips of the benchmark shape) and its
+    logits are compared with those golden logits, in the timed operand dtype and in the other one."""
+    import numpy as np
+    from gava_clip_amd import synth
+    from helpers import synth_torch_state
+    g = np.load(os.path.join(REPO, "tests", "golden", "c1_b16.npz"))
+    log("accuracy: loading the golden run's synthetic weights")
+    keep = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(synth_torch_state(cfg, len(model.tokenized_prompts)), strict=True)
+    x = torch.from_numpy(synth.synth_clip(2, cfg.num_frames, cfg.input_size)).cuda()
+    res = {"reference": "tests/golden/c1_b16.npz (reference fp32 CPU forward, tools/gen_golden.py)", "bar": "1e-3 relative"}
+    for p_ in (prec, "bf16" if prec == "fp16" else "fp16"):
+        model.set_operand_dtype(p_)
+        with torch.no_grad():
+            lg = model(x)[0].float().cpu().numpy()
+        d = np.abs(lg - g["logits"])
+        res[p_] = {"max_abs_err": float(d.max()), "rel_to_max_logit": float(d.max() / np.abs(g["logits"]).max()),
+                   "max_elementwise_rel": float((d / np.abs(g["logits"])).max()),
+                   "argmax_equal": bool((lg.argmax(-1) == g["logits"].argmax(-1)).all())}
+    model.set_operand_dtype(prec)
+    model.load_state_dict(keep, strict=True)
+    return res
+
+
 def cpu_baseline():
     """The oracle (CPU port of the reference forward) at BASELINE config c1: B=2, T=8, 3 classes, fp32."""
     import numpy as np
@@ -253,17 +290,26 @@ def main():
     clips = world * B * a.steps
     value = clips / secs
     fwd_flops = fl.forward_flops(cfg, B, n_cls)
+    exe_flops = fl.executed_flops(cfg, B, n_cls, text_rows=model.text_rows_per_prompt)
 
     out = {
-        "metric": "clips/sec (%d-frame 224^2 ViT-B/16 VitaCLIP.forward)" % cfg.num_frames, "value": round(value, 2), "unit": "clips/s",
+        "metric": "clips/sec (%d-frame 224^2 %s VitaCLIP.forward)" % (cfg.num_frames, "ViT-L/14" if cfg.patch_size == 14 else "ViT-B/16"),
+        "value": round(value, 2), "unit": "clips/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * secs / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.prec, "data": "synthetic",
         "config": {"workload": f"{a.config}: {desc}", "clips_per_gpu": B, "global_batch": B * world,
                    "frames": cfg.num_frames, "classes": n_cls, "weights": "random-init",
                    "parallelism": f"clips sharded over {world} GPU(s); RCCL all-gather of (B,E) embeddings" if world > 1 else "single GPU",
                    "text_tower": "split-precision (3 MFMA passes)" if model.text_split_precision else a.prec},
+        # two FLOP figures: the REFERENCE's dense work for this batch (what a drop-in replaces; includes rows
+        # whose results the reference discards) and the work this path EXECUTES (flops.executed_flops: no prompt-row
+        # q/out/MLP, CLS-only last block, text rows up to the last EOT).  Utilisation is quoted on the executed figure.
         "algorithmic_tflops": round(fwd_flops * world * a.steps / secs / 1e12, 1),
-        "mfma_frac_whole_forward": round(fwd_flops * a.steps / secs / 1e12 / PEAK_MFMA_TFLOPS, 4),
+        "executed_tflops": round(exe_flops * world * a.steps / secs / 1e12, 1),
+        "mfma_frac_executed": round(exe_flops * a.steps / secs / 1e12 / PEAK_MFMA_TFLOPS, 4),
+        "mfma_frac_reference_flops": round(fwd_flops * a.steps / secs / 1e12 / PEAK_MFMA_TFLOPS, 4),
+        "target": {"what": "north_star: >= 40 % MFMA utilisation at c2 = 3370 clips/s at the 2.5 PFLOP/s dense peak",
+                   "met": bool(a.config == "c2" and value / world >= 3370.0)} if a.config == "c2" else None,
     }
     if rank == 0 and not a.no_kernels:
         log("stand-alone kernel timings")
@@ -272,10 +318,16 @@ def main():
         out["kernels"] = [{k: r[k] for k in ("kernel", "ms", "tflops", "gbps")} for r in rows]
         # the roofline kernel is the fc1 GEMM in the form the forward launches it (LayerNorm folded into it or not)
         fc1 = next(r for r in rows if r["kernel"].startswith("gemm fc1  folded" if fold else "gemm fc1"))
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "traffic.json")   # HBM bytes/launch from the committed PMC passes
+        # HBM bytes / launch from the committed PMC passes (tools/make_traffic.py writes them together with a hash of the
+        # kernel sources they were measured on): a file measured on other sources is stale and is NOT reported
+        traffic, traffic_src = None, "profiles/traffic.json missing"
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("gemm_fc1_bytes_per_launch")
+            tj = json.load(open(tpath))
+            if tj.get("kernel_source_sha256") == kernel_source_hash():
+                traffic, traffic_src = tj.get("gemm_fc1_bytes_per_launch"), tj.get("source")
+            else:
+                traffic_src = "profiles/traffic.json is stale (kernel sources changed since its PMC passes): not reported"
         # cross-check where it runs: HIP-event pairs around every fc1 launch inside a few more forwards of the timed
         # workload (gava_probe_fc1_*, on the stream the driver launches on) -> roofline.in_forward_ms_per_launch
         in_fwd = None
@@ -305,6 +357,7 @@ def main():
                                ", FOLD" if fold else "", B * cfg.num_frames * cfg.tokens_main, cfg.mlp_dim, cfg.feature_dim),
                            "achieved": round(fc1["flops"] / fc1_ms / 1e9, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(fc1["flops"] / fc1_ms / 1e9 / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
+                           "traffic_source": traffic_src,
                            "flops_per_launch": fc1["flops"], "ms_per_launch": round(fc1_ms, 4),
                            "timed": "HIP events around 20 back-to-back launches after 10 warm-up launches",
                            # the same kernel bracketed by an event pair per launch inside 5 forwards of the timed workload
@@ -333,7 +386,7 @@ def main():
         model.set_operand_dtype(a.prec)
         if s2 is not None:
             out["alt"] = {"dtype": other, "value": round(B * max(3, a.steps // 4) / s2, 2), "unit": "clips/s"}
-    if rank == 0 and world == 1 and not a.no_train:
+    if rank == 0 and world == 1 and not a.no_train and a.config in ("c2", "c3"):
         # one training step (forward with saved block inputs, loss.backward() through the HIP
         # backward kernels, AdamW on the trainable subset), same batch.  Reported beside the headline, not part of it.
         log("training step")
@@ -350,6 +403,8 @@ def main():
         out["train_step"] = {"ms_per_step": round(1e3 * ts / 3, 1), "value": round(3 * B / ts, 1), "unit": "clips/s",
                              "what": "forward + backward (bf16 gradient operands) + AdamW, %d trainable parameters"
                                      % sum(q.numel() for q in model.parameters() if q.requires_grad)}
+    if rank == 0 and world == 1 and cname == "VIT_B16_T8" and not a.no_accuracy:
+        out["accuracy"] = accuracy_vs_golden(model, cfg, a.prec)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if dist is not None:

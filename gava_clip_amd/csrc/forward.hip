@@ -3,12 +3,16 @@
 #include "common.h"
 #include "internal.h"
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 
-// Second stream for the prompt ("side") path of every block.  Created once on first use (the only
-// allocation the library ever makes); fork/join by events, so a capturing caller records a proper
-// fork-join graph.  GAVA_SIDE_STREAM=0 keeps everything on the caller's stream.
+// Per-device launch context.  The library allocates nothing per call; the only objects it ever creates are, once per
+// device and on first use, a second stream for the prompt ("side") path of every block with its fork/join events (a
+// capturing caller records a proper fork-join graph; GAVA_SIDE_STREAM=0 keeps everything on the caller's stream) and the
+// event pairs of the fc1 probe.  They are keyed by the CURRENT device (the caller's stream must belong to it, as for any
+// HIP launch), and a per-device mutex serialises the drivers' enqueue sequences: two host threads may call into the
+// library concurrently, on the same or on different devices.
 struct SideStream {
   hipStream_t s = nullptr;
   hipEvent_t fork[64], join[64];
@@ -28,18 +32,6 @@ struct SideStream {
     return true;
   }
 };
-SideStream g_side;
-
-// CUs the persistent QKV GEMM leaves to the prompt-path kernels on the side stream.  Measured (tools/side_probe.py): with
-// 8 or 16 CUs left out a 128-workgroup kernel on the second stream still waits for the GEMM's first workgroups to retire
-// (0.23 ms instead of 0.01 ms) - workgroups are dealt round-robin to the XCDs' shader engines and the dispatch blocks on
-// the first engine without a free CU; with 32 (one CU per engine) it runs at its stand-alone speed and the GEMM is 4 % slower.
-// When LN1 runs before the QKV GEMM most of the prompt path finishes beside LN1 and only its tail waits: 8 is then the
-// better trade (23.85 vs 24.0 ms per forward); with LN1 folded away the whole path sits beside the GEMM: 32 (23.4 vs 23.75).
-int side_cus(bool ln1_folded) {
-  static const int forced = getenv("GAVA_SIDE_CUS") ? atoi(getenv("GAVA_SIDE_CUS")) : -1;
-  return forced >= 0 ? forced : (ln1_folded ? 32 : 8);
-}
 
 // fc1 probe (gava_probe_fc1_enable / _read): event pairs around the roofline kernel inside the forward
 struct Fc1Probe {
@@ -55,7 +47,30 @@ struct Fc1Probe {
     return true;
   }
 };
-Fc1Probe g_probe;
+
+constexpr int MAX_DEVICES = 64;
+struct DeviceCtx {
+  std::mutex mu;
+  SideStream side;
+  Fc1Probe probe;
+};
+DeviceCtx g_dev[MAX_DEVICES];
+DeviceCtx& device_ctx() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+  return g_dev[d % MAX_DEVICES];
+}
+
+// CUs the persistent QKV GEMM leaves to the prompt-path kernels on the side stream.  Measured (tools/side_probe.py): with
+// 8 or 16 CUs left out a 128-workgroup kernel on the second stream still waits for the GEMM's first workgroups to retire
+// (0.23 ms instead of 0.01 ms) - workgroups are dealt round-robin to the XCDs' shader engines and the dispatch blocks on
+// the first engine without a free CU; with 32 (one CU per engine) it runs at its stand-alone speed and the GEMM is 4 % slower.
+// When LN1 runs before the QKV GEMM most of the prompt path finishes beside LN1 and only its tail waits: 8 is then the
+// better trade (23.85 vs 24.0 ms per forward); with LN1 folded away the whole path sits beside the GEMM: 32 (23.4 vs 23.75).
+int side_cus(bool ln1_folded) {
+  static const int forced = getenv("GAVA_SIDE_CUS") ? atoi(getenv("GAVA_SIDE_CUS")) : -1;
+  return forced >= 0 ? forced : (ln1_folded ? 32 : 8);
+}
 
 struct Carver {
   char* base; size_t off, cap;
@@ -90,8 +105,9 @@ struct Fold {
 
 int gemm(const void* A, long lda, const void* W, long ldw, const float* bias, void* out, long ldo, int M, int N, int K,
          int epi, int prec, gava_stream_t s, const float* resid = nullptr, long ldr = 0, int scale_cols = 0,
-         float scale = 1.f, int split_out = 0, void* aux_out = nullptr, const Fold* fold = nullptr) {
+         float scale = 1.f, int split_out = 0, void* aux_out = nullptr, const Fold* fold = nullptr, int cu_reserve = 0) {
   gava_gemm_args a{};
+  a.cu_reserve = cu_reserve;
   if (fold) {
     a.x16_out = fold->x16; a.ld_x16 = fold->ld_x16; a.rowsum_out = fold->rowsum;
     a.fold_stats = fold->stats; a.fold_s = fold->s; a.fold_t = fold->t;
@@ -133,10 +149,10 @@ VisionWs carve_vision(const gava_vision_model* m, void* ws, size_t cap) {
   w.SIDEKV = c.take(SR * 2 * D * 2);
   w.CLSPOST = c.take(BT * 3 * D * 2);
   w.PROJ = (float*)c.take(BT * E * 4);
-  w.XNC = c.take(BT * D * 2);
+  w.XNC = c.take(BT * 3 * D * 2);     // x3: the last block's CLS rows may run in split precision ([hi | lo | hi] rows)
   w.QC = c.take(BT * D * 2);
-  w.MIXC = c.take(BT * D * 2);
-  w.HIDC = c.take(BT * F * 2);
+  w.MIXC = c.take(BT * 3 * D * 2);
+  w.HIDC = c.take(BT * 3 * F * 2);
   w.RSUM = (float*)c.take(R * (D / 64) * 8);
   w.STATS = (float*)c.take((R + 255) / 256 * 256 * 8);
   w.total = (c.off + 255) & ~(size_t)255;
@@ -158,8 +174,12 @@ int check_vision(const gava_vision_model* m) {
 
 extern "C" int gava_abi_version(void) { return 1; }
 
-extern "C" int gava_probe_fc1_enable(int on) { g_probe.on = on != 0; if (!on) g_probe.n = 0; return GAVA_OK; }
+extern "C" int gava_probe_fc1_enable(int on) {
+  Fc1Probe& g_probe = device_ctx().probe;
+  g_probe.on = on != 0; if (!on) g_probe.n = 0; return GAVA_OK;
+}
 extern "C" int gava_probe_fc1_read(float* ms, int cap) {
+  Fc1Probe& g_probe = device_ctx().probe;
   const int n = g_probe.n;
   if (n <= 0 || !ms) return 0;
   if (hipEventSynchronize(g_probe.ev[n - 1][1]) != hipSuccess) return 0;
@@ -186,7 +206,10 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
   const VisionWs w = carve_vision(m, workspace, workspace_bytes);
   if (w.total > workspace_bytes) return GAVA_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  gava::set_gemm_cu_reserve(0);
+  DeviceCtx& dc = device_ctx();
+  std::lock_guard<std::mutex> lock(dc.mu);
+  SideStream& g_side = dc.side;
+  Fc1Probe& g_probe = dc.probe;
   const int g = m->size / m->P, n = g * g, BT = m->B * m->T_in, R = BT * (n + 1);
   const int D = m->D, F = m->F, E = m->E, G = m->G, Tm = m->T_model, pr = m->prec;
   const int Kp = patch_k(m), SR = G + 2 * BT;
@@ -244,7 +267,7 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
     TRY(gava::side_ln(L.global_prompts, L.local_prompts, w.CP, w.SUMM, L.ln1_g, L.ln1_b, w.SIDEn, G, Tm, BT, D, pr, (hipStream_t)ss));
     TRY(gemm(w.SIDEn, D, wqkv + (long)D * D, D, L.b_qkv + D, w.SIDEKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, ss));
     if (two && hipEventRecord(g_side.join[i], g_side.s) != hipSuccess) return GAVA_ELAUNCH;
-    gava::set_gemm_cu_reserve(two ? side_cus(folded_in) : 0);   // the persistent QKV GEMM leaves side_cus() CUs to the side kernels
+    const int resv = two ? side_cus(folded_in) : 0;   // the persistent QKV GEMM leaves side_cus() CUs to the side kernels
     // main path.  LayerNorm folding (inference only, when the model carries the folded weights): norm2 of every block
     // but the last and norm1 of blocks 1..layers-2 are not launched; the producing GEMM (out_proj / fc2 of the block
     // before) leaves a 16-bit copy of x in Xn plus row-sum partials, gava_row_stats makes (mean, rstd) of them and the
@@ -259,10 +282,9 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
     if (not_last) {
       if (fold1) {
         Fold c; c.stats = w.STATS; c.s = L.qkv_fold_s; c.t = L.qkv_fold_t;
-        TRY(gemm(w.Xn, D, L.w_qkv_fold, D, nullptr, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, &c));
+        TRY(gemm(w.Xn, D, L.w_qkv_fold, D, nullptr, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, &c, resv));
       } else
-      TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
-      gava::set_gemm_cu_reserve(0);
+      TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, nullptr, resv));
       if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
       {
         gava_attention_args a{};
@@ -301,9 +323,16 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       // takes x[:,0]; the summary token comes from the prompt path above).  Keys/values are still
       // needed for every token, queries / out_proj / MLP only for the B*T CLS rows: same results,
       // 1/197 of the row work.
-      TRY(gemm(w.Xn, D, wqkv + (long)D * D, D, L.b_qkv + D, (unsigned short*)w.QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream));
-      TRY(gemm(w.Xn, fs, L.w_qkv, D, L.b_qkv, w.QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
-      gava::set_gemm_cu_reserve(0);
+      TRY(gemm(w.Xn, D, wqkv + (long)D * D, D, L.b_qkv + D, (unsigned short*)w.QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, nullptr, resv));
+      // split precision for these B*T rows when the model carries the split-packed weights (gava_vision_layer)
+      const int sp = (!saved_x && L.w_q_split && L.w_out_split && L.w_fc1_split && L.w_fc2_split) ? 1 : 0;
+      const int S = sp ? 3 : 1;
+      if (sp) {
+        TRY(ln(w.X, fs, nullptr, L.ln1_g, L.ln1_b, w.XNC, 3 * D, nullptr, 0, BT, D, pr, stream, 1));
+        TRY(gemm(w.XNC, 3 * D, L.w_q_split, 3 * D, L.b_qkv, w.QC, D, BT, D, 3 * D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+      } else {
+        TRY(gemm(w.Xn, fs, L.w_qkv, D, L.b_qkv, w.QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+      }
       if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
       {
         gava_attention_args a{};
@@ -311,15 +340,15 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
         a.q = w.QC; a.ld_q = D; a.q_batch_rows = 1;
         a.k = q + D; a.v = q + 2 * D; a.ld_qkv = 3 * D;
         a.side_k = sk; a.side_v = sk + D; a.ld_side = 2 * D;
-        a.out = w.MIXC; a.ld_out = D;
+        a.out = w.MIXC; a.ld_out = S * D; a.split_out = sp;
         a.batch = BT; a.heads = m->H; a.n_q = 1; a.n_kmain = n + 1;
         a.n_g = G; a.T = Tm; a.has_summary = 1; a.prec = pr;
         TRY(gava_attention(&a, stream));
       }
-      TRY(gemm(w.MIXC, D, L.w_out, D, L.b_out, w.X, fs, BT, D, D, GAVA_EPI_F32, pr, stream, w.X, fs));
-      TRY(ln(w.X, fs, nullptr, L.ln2_g, L.ln2_b, w.XNC, D, nullptr, 0, BT, D, pr, stream));
-      TRY(gemm(w.XNC, D, L.w_fc1, D, L.b_fc1, w.HIDC, F, BT, F, D, GAVA_EPI_H16_QGELU, pr, stream));
-      TRY(gemm(w.HIDC, F, L.w_fc2, F, L.b_fc2, w.X, fs, BT, D, F, GAVA_EPI_F32, pr, stream, w.X, fs));
+      TRY(gemm(w.MIXC, S * D, sp ? L.w_out_split : L.w_out, S * D, L.b_out, w.X, fs, BT, D, S * D, GAVA_EPI_F32, pr, stream, w.X, fs));
+      TRY(ln(w.X, fs, nullptr, L.ln2_g, L.ln2_b, w.XNC, S * D, nullptr, 0, BT, D, pr, stream, sp));
+      TRY(gemm(w.XNC, S * D, sp ? L.w_fc1_split : L.w_fc1, S * D, L.b_fc1, w.HIDC, S * F, BT, F, S * D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, sp));
+      TRY(gemm(w.HIDC, S * F, sp ? L.w_fc2_split : L.w_fc2, S * F, L.b_fc2, w.X, fs, BT, D, S * F, GAVA_EPI_F32, pr, stream, w.X, fs));
     }
     if (debug_cls) TRY(gava::copy_rows(w.X, fs, debug_cls + (long)i * BT * D, BT, D, s));
   }
@@ -348,7 +377,9 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
   const VisionWs w = carve_vision(m, workspace, workspace_bytes);
   if (w.total > workspace_bytes) return GAVA_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  gava::set_gemm_cu_reserve(0);
+  DeviceCtx& dc = device_ctx();
+  std::lock_guard<std::mutex> lock(dc.mu);
+  SideStream& g_side = dc.side;
   const int g = m->size / m->P, n = g * g, BT = m->B * m->T_in, R = BT * (n + 1);
   const int D = m->D, F = m->F, E = m->E, G = m->G, Tm = m->T_model, pr = m->prec;
   const int Kp = patch_k(m), SR = G + 2 * BT;
@@ -394,7 +425,7 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
     TRY(gava::side_ln(L.global_prompts, L.local_prompts, w.CP, w.SUMM, L.ln1_g, L.ln1_b, w.SIDEn, G, Tm, BT, D, pr, (hipStream_t)ss));
     TRY(gemm(w.SIDEn, D, wqkv + (long)D * D, D, L.b_qkv + D, SKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, ss));
     if (two && hipEventRecord(g_side.join[i], g_side.s) != hipSuccess) return GAVA_ELAUNCH;
-    gava::set_gemm_cu_reserve(two ? side_cus(false) : 0);
+    const int resv = two ? side_cus(false) : 0;
     TRY(ln(Xin, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
     if (i + 1 == m->layers && sv->last_q && sv->last_x1 && sv->last_pre) {
       // Last block, as in the inference driver: keys/values for every row, queries / out_proj / MLP for the B*T CLS
@@ -402,9 +433,8 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
       // rows of the stream after attention, the CLS pre-activations.
       unsigned short* QC = (unsigned short*)sv->last_q;
       unsigned short* PREC = (unsigned short*)sv->last_pre;
-      TRY(gemm(w.Xn, D, wqkv + (long)D * D, D, L.b_qkv + D, QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream));
+      TRY(gemm(w.Xn, D, wqkv + (long)D * D, D, L.b_qkv + D, QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, nullptr, resv));
       TRY(gemm(w.Xn, fs, L.w_qkv, D, L.b_qkv, QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
-      gava::set_gemm_cu_reserve(0);
       if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
       {
         gava_attention_args a{};
@@ -422,8 +452,7 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
       TRY(gemm(w.HIDC, F, L.w_fc2, F, L.b_fc2, Xout, fs, BT, D, F, GAVA_EPI_F32, pr, stream, sv->last_x1, D));
       continue;
     }
-    TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
-    gava::set_gemm_cu_reserve(0);
+    TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, nullptr, resv));
     if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
     {
       gava_attention_args a{};
@@ -469,7 +498,9 @@ int check_text(const gava_text_model* m) {
   if (!m || !m->layer) return GAVA_EINVAL;
   if (m->n_prompts <= 0 || m->L <= 0 || m->L > 320 || m->layers <= 0) return GAVA_EINVAL;
   if (m->W != m->H * 64 || m->W % 128 || m->E % 128 || m->W > 1024) return GAVA_EINVAL;
-  if (m->n_ctx < 0 || m->n_ctx + 1 >= m->L) return GAVA_EINVAL;
+  // L == n_ctx + 1 is a valid trimmed length: knowledge-aware prompts without descriptions put the EOT look-up inside
+  // the context slots (text_encoder.py:169,298), and text_embed_kernel handles a prompt that ends with its context
+  if (m->n_ctx < 0 || m->n_ctx + 1 > m->L) return GAVA_EINVAL;
   return GAVA_OK;
 }
 }  // namespace
@@ -489,7 +520,7 @@ extern "C" int gava_text_forward_train(const gava_text_model* m, const int32_t* 
                                        const int32_t* eot_index, float* out, float* saved_x, void* workspace,
                                        size_t workspace_bytes, gava_stream_t stream) {
   TRY(check_text(m));
-  if (!tokens || !ctx || !eot_index || !out || !workspace) return GAVA_EINVAL;
+  if (!ctx || !eot_index || !out || !workspace) return GAVA_EINVAL;   // tokens == NULL: direct mode (gava_hip.h)
   const TextWs w = carve_text(m, workspace, workspace_bytes);
   if (w.total > workspace_bytes) return GAVA_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;

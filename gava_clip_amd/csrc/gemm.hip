@@ -57,6 +57,7 @@ struct GemmParams {
   int split_out;
   int sm, sn;   // super-tile shape (in tiles)
   unsigned long long* dbg;  // debug only: per-wave segment cycle sums (gava_debug_set_buffer)
+  int cu_reserve;   // persistent kernels: CUs left out of the grid (gava_gemm_args.cu_reserve)
   int ablate;   // timing probes, always 0 unless built with -DGAVA_ENABLE_ABLATE: 1 = no staging loads after the prologue,
                 // 2 = no LDS reads/MFMA, 4 = no epilogue
 };
@@ -1109,7 +1110,10 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
     n_cu = prop.multiProcessorCount / 8 * 8;
     if (n_cu <= 0) n_cu = 8;
   }
-  const int avail = n_cu - gava::gemm_cu_reserve() > 8 ? (n_cu - gava::gemm_cu_reserve()) / 8 * 8 : 8;
+  // GAVA_CU_RESERVE (diagnostics, tools/side_probe.py) overrides what the caller asks for
+  static const int forced = getenv("GAVA_CU_RESERVE") ? atoi(getenv("GAVA_CU_RESERVE")) : -1;
+  const int reserve = forced >= 0 ? forced : (gp.cu_reserve > 0 ? gp.cu_reserve : 0);
+  const int avail = n_cu - reserve > 8 ? (n_cu - reserve) / 8 * 8 : 8;
   const int blocks = gp.n_tiles < avail ? (gp.n_tiles + 7) / 8 * 8 : avail;
   dim3 grid(blocks), block(512);
 #define GAVA_LAUNCH(EPI, RES, SPLIT)                                                               \
@@ -1214,6 +1218,7 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.pos = a->pos; gp.time = a->time; gp.n_patches = a->n_patches; gp.T = a->T;
   gp.frames = patch_direct ? a->frames : nullptr; gp.fsize = a->frame_size; gp.patch = a->patch;
   gp.split_out = a->split_out;
+  gp.cu_reserve = a->cu_reserve;
 #ifdef GAVA_ENABLE_ABLATE   // timing-probe builds only (tools/ab_build.sh NAME -DGAVA_ENABLE_ABLATE): results are WRONG by design
   static const int ablate = getenv("GAVA_GEMM_ABLATE") ? atoi(getenv("GAVA_GEMM_ABLATE")) : 0;
   gp.ablate = ablate;

@@ -10,7 +10,7 @@ int mean_rows(const float* in, float* out, int B, int T, int D, hipStream_t s);
 int copy_rows(const float* in, long in_stride, float* out, int rows, int D, hipStream_t s);
 int text_embed(const float* emb, const float* pos, const float* ctx, const int* tok, float* X,
                int n_prompts, int L, int W, int n_ctx, hipStream_t s);
-unsigned long long* debug_buffer();
+unsigned long long* debug_buffer();   // set by gava_debug_set_buffer; nullptr = stamps off
 
 // MFMA attention backward (attention_bwd.hip), launched by gava_attention_backward (backward.hip)
 struct AttnBwdMfmaParams {
@@ -25,7 +25,4 @@ struct AttnBwdMfmaParams {
   float q_scale;
 };
 int attention_bwd_mfma(const AttnBwdMfmaParams& p, int prec, int act_prec, int causal, hipStream_t s);
-// CUs the persistent GEMM leaves free on its next launches (so a concurrent stream can run small kernels)
-void set_gemm_cu_reserve(int n);
-int gemm_cu_reserve();   // set by gava_debug_set_buffer; nullptr = stamps off
 }  // namespace gava

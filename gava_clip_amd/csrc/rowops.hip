@@ -177,7 +177,8 @@ __global__ void text_embed_kernel(const float* emb, const float* pos, const floa
   const int l = (int)(row % L);
   const long n = row / L;
   float v;
-  if (l >= 1 && l <= n_ctx) v = ctx[(n * n_ctx + (l - 1)) * W + c];
+  if (!tok) v = ctx[id];                        // direct mode: ctx holds the whole (n, L, W) prompt embeddings
+  else if (l >= 1 && l <= n_ctx) v = ctx[(n * n_ctx + (l - 1)) * W + c];
   else v = emb[(long)tok[n * L + l] * W + c];
   X[id] = v + pos[(long)l * W + c];
 }
@@ -337,15 +338,8 @@ extern "C" int gava_debug_set_buffer(void* dev_u64) {
   g_debug_buffer = (unsigned long long*)dev_u64;
   return GAVA_OK;
 }
-static int g_cu_reserve = 0;
 namespace gava {
-unsigned long long* debug_buffer() { return g_debug_buffer; }
-void set_gemm_cu_reserve(int n) { g_cu_reserve = n; }
-int gemm_cu_reserve() {
-  // GAVA_CU_RESERVE (diagnostics, tools/side_probe.py): overrides what the drivers ask for
-  static const int forced = getenv("GAVA_CU_RESERVE") ? atoi(getenv("GAVA_CU_RESERVE")) : -1;
-  return forced >= 0 ? forced : g_cu_reserve;
-}
+unsigned long long* debug_buffer() { return g_debug_buffer; }   // diagnostics only (tools/gemm_stamps.py); nullptr = stamps off
 }
 
 // ---- internal launchers used by the fused drivers -------------------------------------------

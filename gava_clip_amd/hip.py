@@ -35,7 +35,7 @@ class GemmArgs(C.Structure):
                 ("frames", _fp), ("frame_size", C.c_int), ("patch", C.c_int), ("split_out", C.c_int),
                 ("aux", _vp), ("aux_prec", C.c_int), ("aux_out", _vp),
                 ("x16_out", _vp), ("ld_x16", C.c_int64), ("rowsum_out", _fp),
-                ("fold_stats", _fp), ("fold_s", _fp), ("fold_t", _fp)]
+                ("fold_stats", _fp), ("fold_s", _fp), ("fold_t", _fp), ("cu_reserve", C.c_int)]
 
 
 class LayerNormArgs(C.Structure):
@@ -59,7 +59,8 @@ class VisionLayer(C.Structure):
         "w_qkv", "b_qkv", "w_out", "b_out", "w_fc1", "b_fc1", "w_fc2", "b_fc2",
         "ln1_g", "ln1_b", "ln2_g", "ln2_b", "w_cls", "b_cls", "sln_g", "sln_b",
         "w_sqkv", "b_sqkv", "w_sout", "b_sout", "local_prompts", "global_prompts",
-        "w_qkv_fold", "qkv_fold_s", "qkv_fold_t", "w_fc1_fold", "fc1_fold_s", "fc1_fold_t")]
+        "w_qkv_fold", "qkv_fold_s", "qkv_fold_t", "w_fc1_fold", "fc1_fold_s", "fc1_fold_t",
+        "w_q_split", "w_out_split", "w_fc1_split", "w_fc2_split")]
 
 
 class VisionModel(C.Structure):
@@ -184,8 +185,11 @@ def check(code, what):
         raise GavaError(f"{what} failed: {_ERR.get(code, code)}")
 
 
-def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(device=None):
+    """torch's current HIP stream on `device` (default: the current device).  The drivers key their per-device launch
+    context by the CURRENT device, so callers that may be handed a tensor of another device wrap the call in
+    `torch.cuda.device(t.device)` (model.py does)."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def ptr(t):
@@ -204,8 +208,10 @@ def h16_dtype(prec):
 
 def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0,
          pos=None, time=None, n_patches=0, T=0, M=None, split_out=False, frames=None, frame_size=0, patch=0, aux=None,
-         aux_prec=None, aux_out=None, x16_out=None, rowsum_out=None, fold_stats=None, fold_s=None, fold_t=None):
+         aux_prec=None, aux_out=None, x16_out=None, rowsum_out=None, fold_stats=None, fold_s=None, fold_t=None,
+         cu_reserve=0):
     a = GemmArgs()
+    a.cu_reserve = cu_reserve
     a.x16_out, a.ld_x16, a.rowsum_out = ptr(x16_out), (x16_out.stride(0) if x16_out is not None else 0), ptr(rowsum_out)
     a.fold_stats, a.fold_s, a.fold_t = ptr(fold_stats), ptr(fold_s), ptr(fold_t)
     a.aux, a.aux_out = ptr(aux), ptr(aux_out)

@@ -14,6 +14,7 @@ fallback: a non-device input or a missing library raises.
 import ctypes as C
 import math
 import os
+import weakref
 from collections import OrderedDict
 from typing import List, Tuple
 
@@ -34,6 +35,25 @@ NUM_COMB = 70  # /root/reference/video_dataset/dataset.py:19
 class _Params(nn.Module):
     def forward(self, *a, **k):  # pragma: no cover - never called
         raise RuntimeError("gava_clip_amd sub-modules hold parameters only; call VitaCLIP.forward")
+
+
+class _Encoder(_Params):
+    """The two L1 encoders of the reference are callable on their own (`videoEncoder(data)`, evaluation/iwa.py:212,230;
+    `text_model(token_features, tokenized_prompts)`, evaluation/zero_shot.py:75-76, utils/prepare_embedding.py): forward()
+    hands the call to the HIP host that packs this encoder's weights - the VitaCLIP it belongs to, or a private one when
+    the encoder was constructed stand-alone."""
+
+    def _host(self):
+        ref = self.__dict__.get("_host_ref")
+        host = ref() if ref is not None else None
+        if host is not None and getattr(host, "visual", None) is not self and getattr(host, "textual", None) is not self:
+            host = None          # a deep copy still pointing at the model it was copied from
+        if host is None:
+            host = self.__dict__.get("_own_host")
+            if host is None:
+                host = _StandaloneHost(self)
+                self.__dict__["_own_host"] = host
+        return host
 
 
 class Attention(_Params):
@@ -83,13 +103,24 @@ class _PatchEmbed(_Params):
         self.proj = nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
 
 
-class CLIPVisionEncoder(_Params):
-    """VitaCLIP_vision_encoder.py:19-84."""
+class CLIPVisionEncoder(_Encoder):
+    """VitaCLIP_vision_encoder.py:19-84 (same constructor keywords); forward(x) -> (cls_x (B,E), summary (B,D)), :102-132."""
 
-    def __init__(self, input_size, num_frames, feature_dim, patch_size, num_heads, num_layers, mlp_factor,
-                 embed_dim, num_global_prompts):
+    def __init__(self, input_size=(224, 224), num_frames=8, feature_dim=768, patch_size=(16, 16), num_heads=12,
+                 num_layers=12, mlp_factor=4.0, act=None, embed_dim=512, use_summary_token=False, use_local_prompts=False,
+                 use_global_prompts=False, num_global_prompts=8):
         super().__init__()
+        if not (use_summary_token and use_local_prompts and use_global_prompts):
+            raise NotImplementedError("only use_summary_token=use_local_prompts=use_global_prompts=True is a working "
+                                      "configuration of the reference (VitaCLIP_vision_encoder.py:123-124,129)")
+        if isinstance(input_size, int):
+            input_size = (input_size, input_size)
+        if isinstance(patch_size, int):
+            patch_size = (patch_size, patch_size)
         self.feature_dim = feature_dim
+        self.num_frames = num_frames
+        self._hip_shape = dict(size=input_size[0], P=patch_size[0], D=feature_dim, H=num_heads, layers=num_layers,
+                               F=round(mlp_factor * feature_dim), E=embed_dim, G=num_global_prompts)
         self.patch_embed = _PatchEmbed(patch_size[0], feature_dim)
         self.num_patches = int(np.prod([x // y for x, y in zip(input_size, patch_size)])) + 1
         self.cls_token = nn.Parameter(torch.zeros([feature_dim]))
@@ -108,6 +139,9 @@ class CLIPVisionEncoder(_Params):
         nn.init.normal_(self.cls_token, std=0.02)
         nn.init.normal_(self.pos_embed, std=0.02)
         nn.init.normal_(self.time_embed, std=0.02)
+
+    def forward(self, x):
+        return self._host().encode_video(x)
 
 
 class _MHAParams(_Params):
@@ -139,13 +173,16 @@ class Transformer(_Params):
         self.resblocks = nn.ModuleList([ResidualAttentionBlock(width) for _ in range(layers)])
 
 
-class CLIPTextEncoder(_Params):
+class CLIPTextEncoder(_Encoder):
     """VitaCLIP_text_encoder.py:120-143.  positional_embedding / text_projection are
     ``torch.empty`` upstream (uninitialised without a checkpoint); here they get the CLIP
     initialisers so that a random-weight model is finite."""
 
-    def __init__(self, embed_dim, context_length, vocab_size, transformer_width, transformer_heads, transformer_layers):
+    def __init__(self, embed_dim=512, context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8,
+                 transformer_layers=12):
         super().__init__()
+        self._hip_shape = dict(W=transformer_width, TH=transformer_heads, TL=transformer_layers, L=context_length,
+                               E=embed_dim, n_ctx=0)
         self.context_length = context_length
         self.transformer = Transformer(transformer_width, transformer_layers)
         self.heads = transformer_heads
@@ -156,6 +193,10 @@ class CLIPTextEncoder(_Params):
         self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
         nn.init.normal_(self.positional_embedding, std=0.01)
         nn.init.normal_(self.text_projection, std=transformer_width ** -0.5)
+
+    def forward(self, prompts, tokenized_prompts):
+        """(n, L, W) prompt embeddings + (n, L) token ids -> (n, E) (VitaCLIP_text_encoder.py:154-171)."""
+        return self._host().encode_prompt_embeddings(prompts, tokenized_prompts)
 
 
 class ContextualPromptLearner(nn.Module):
@@ -291,8 +332,386 @@ class TextPromptLearner(_Params):
         return self.ctx
 
 
+class _HipHost:
+    """Weight packing and tower launches on libgava_hip.so, shared by VitaCLIP and by stand-alone encoders.  Expects
+    `visual` and / or `textual` attributes (parameter containers), `num_frames`, and the nn.Module parameter iterators."""
+
+    def _hip_init(self, shape, operand_dtype=None):
+        operand_dtype = operand_dtype or os.environ.get("GAVA_PREC", "fp16")
+        self.prec = hip.PREC_NAMES[operand_dtype]
+        # text tower GEMMs in split precision (hi+lo operands, 3 MFMA passes): the text side is <1 % of
+        # the work at the headline configs but dominates the logits error at plain 16-bit operands
+        self.text_split_precision = os.environ.get("GAVA_TEXT_SPLIT", "1") != "0"
+        # eval-time text-feature cache (SURVEY.md §8f row 2): in eval mode the text tower is input
+        # independent; opt-in because a benchmark must not skip work.  Invalidated by any parameter update.
+        self.cache_text_features = False
+        self.text_on_side_stream = os.environ.get("GAVA_TEXT_STREAM", "1") != "0"
+        # inference: LayerNorm folded into the qkv / fc1 GEMMs (two row passes per block less); GAVA_LN_FOLD=0 turns it off
+        self.fold_layernorm = os.environ.get("GAVA_LN_FOLD", "1") != "0"
+        self.trim_text_rows = os.environ.get("GAVA_TEXT_TRIM", "1") != "0"   # skip the rows behind the last EOT (see _pack)
+        # inference, opt-in: the last block's B*T CLS rows (the only ones that reach the outputs) in split precision.
+        # Measured at c1 (tools/r2_diag.py): video-feature rms error 2.06e-5 with, 2.10e-5 without - the error of the
+        # features is made in the fp16 K/V and in the eleven blocks before, not here - so it is off by default.
+        self.split_last_block = os.environ.get("GAVA_LAST_SPLIT", "0") != "0"
+        self.text_rows_per_prompt = shape.get("L", 77)
+        # training: keep the backward's activations (~21 GB at B = 64, T = 8) instead of recomputing them per block, as
+        # long as they fit this budget; beyond it the backward recomputes from the block inputs only
+        self.keep_activation_bytes = int(float(os.environ.get("GAVA_KEEP_ACT_GB", "96")) * 2 ** 30)
+        self._text_stream = None
+        self._text_cache = None
+        self.gather_across_ranks = True     # RCCL all-gather of clip embeddings when world_size > 1
+        self.shard_text_across_ranks = True  # eval, world_size > 1: each rank encodes a slice of the prompts (+ all-gather)
+        self.debug_taps = False             # keep per-layer CLS rows of the last forward
+        self._shape = dict(shape)
+        self._packed = None
+        self._packed_key = None
+        self._ws = {}
+        self.last = {}
+
+    # ---- weight packing -----------------------------------------------------------------------
+    def set_operand_dtype(self, name: str):
+        self.prec = hip.PREC_NAMES[name]
+        self._packed = None
+
+    _PASS_THROUGH = ("prompt_learner.", "logit_scale", "global_prompts", "local_prompts", "token_embedding",
+                     "pos_embed", "time_embed", "positional_embedding", "cls_token", "sum_proj", "tf_project",
+                     "memory_project")
+
+    def _pack_key(self):
+        """Changes when a packed 16-bit copy goes stale.  fp32 pass-through parameters (prompts, embeddings, LN
+        affines, biases: the structs hold pointers into their own storage) only count by address, so an optimizer
+        step on the prompt parameters does not re-convert 180 M frozen weights."""
+        ver, addr = 0, 0
+        for name, p in self.named_parameters():
+            addr ^= p.data_ptr()
+            if p.dim() >= 2 and not p.requires_grad and not any(k in name for k in self._PASS_THROUGH):
+                ver += p._version
+        if self.fold_layernorm and hasattr(self, "visual"):   # norm1 / norm2 affines and the qkv / fc1 biases are baked into the folded copies
+            for blk in self.visual.blocks:
+                for q in (blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias, blk.attn.q_proj.bias,
+                          blk.attn.k_proj.bias, blk.attn.v_proj.bias, blk.mlp.fc1.bias):
+                    ver += q._version
+        ps = next(self.parameters())
+        return (self.prec, self.text_split_precision, self.trim_text_rows, self.fold_layernorm, self.split_last_block,
+                ps.device, addr, ver)
+
+    def _summary_weight_versions(self):
+        """Versions of the only TRAINABLE weights that have 16-bit copies (summary_attn_layer projections): an optimizer
+        step refreshes just those copies in place (same device pointers) instead of re-converting every frozen weight."""
+        if not hasattr(self, "visual"):
+            return []
+        return [tuple(w._version for w in (b.summary_attn_layer.q_proj.weight, b.summary_attn_layer.k_proj.weight,
+                                           b.summary_attn_layer.v_proj.weight, b.summary_attn_layer.out_proj.weight,
+                                           b.summary_attn_layer.q_proj.bias, b.summary_attn_layer.k_proj.bias,
+                                           b.summary_attn_layer.v_proj.bias))
+                for b in self.visual.blocks]
+
+    def _refresh_summary_weights(self, packed):
+        cur = self._summary_weight_versions()
+        if cur == packed["summary_ver"]:
+            return
+        for i, blk in enumerate(self.visual.blocks):
+            if cur[i] != packed["summary_ver"][i]:
+                s_ = blk.summary_attn_layer
+                packed["w_sqkv"][i].copy_(self._h16(torch.cat([s_.q_proj.weight, s_.k_proj.weight, s_.v_proj.weight], 0)))
+                packed["w_sout"][i].copy_(self._h16(s_.out_proj.weight))
+                packed["b_sqkv"][i].copy_(torch.cat([s_.q_proj.bias, s_.k_proj.bias, s_.v_proj.bias], 0).detach().float())
+        packed["summary_ver"] = cur
+
+    def _pack_vision_backward(self):
+        from . import training
+        key = self._pack_key()
+        if getattr(self, "_bwd_pack_v", None) is None or self._bwd_pack_v[0] != key:
+            self._bwd_pack_v = (key, training.pack_vision_backward(self))
+        training.refresh_vision_backward(self, self._bwd_pack_v[1])
+        return self._bwd_pack_v[1]
+
+    def _pack_text_backward(self):
+        from . import training
+        key = self._pack_key()
+        if getattr(self, "_bwd_pack", None) is None or self._bwd_pack[0] != key:
+            self._bwd_pack = (key, training.pack_text_backward(self))
+        return self._bwd_pack[1]
+
+    def _h16(self, t):
+        return hip.convert_h16(t.detach().float(), self.prec)
+
+    def _f32(self, t):
+        return t.detach().float().contiguous()
+
+    def _pack(self):
+        key = self._pack_key()
+        if self._packed is not None and self._packed_key == key:
+            self._refresh_summary_weights(self._packed)
+            return self._packed
+        sh = self._shape
+        keep = []  # tensors referenced by raw pointers in the structs
+        w_sqkv_t, w_sout_t, b_sqkv_t = [], [], []
+
+        def K(t):
+            keep.append(t)
+            return C.c_void_p(t.data_ptr())
+
+        packed = dict(keep=keep, summary_ver=self._summary_weight_versions())
+        if hasattr(self, "visual"):
+            self._pack_vision(packed, K, w_sqkv_t, w_sout_t, b_sqkv_t)
+        if hasattr(self, "textual"):
+            self._pack_text(packed, K)
+        self._packed, self._packed_key = packed, key
+        return packed
+
+    def _pack_vision(self, packed, K, w_sqkv_t, w_sout_t, b_sqkv_t):
+        sh, v = self._shape, self.visual
+        Kp = (3 * sh["P"] ** 2 + 63) // 64 * 64
+        wpatch = v.patch_embed.proj.weight.detach().float().reshape(sh["D"], -1)
+        if Kp != wpatch.shape[1]:
+            wpatch = F.pad(wpatch, (0, Kp - wpatch.shape[1]))
+        vis = dict(w_patch=K(self._h16(wpatch)), b_patch=K(self._f32(v.patch_embed.proj.bias)),
+                   cls_token=K(self._f32(v.cls_token)), pos_embed=K(self._f32(v.pos_embed)),
+                   lnpre_g=K(self._f32(v.ln_pre.weight)), lnpre_b=K(self._f32(v.ln_pre.bias)),
+                   lnpost_g=K(self._f32(v.ln_post.weight)), lnpost_b=K(self._f32(v.ln_post.bias)),
+                   w_proj=K(hip.split_pack_weight(v.proj.detach().float().t(), self.prec)))
+        layers = (hip.VisionLayer * sh["layers"])()
+        for i, blk in enumerate(v.blocks):
+            a, s = blk.attn, blk.summary_attn_layer
+            L = layers[i]
+            L.w_qkv = K(self._h16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)))
+            L.b_qkv = K(self._f32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)))
+            L.w_out, L.b_out = K(self._h16(a.out_proj.weight)), K(self._f32(a.out_proj.bias))
+            L.w_fc1, L.b_fc1 = K(self._h16(blk.mlp.fc1.weight)), K(self._f32(blk.mlp.fc1.bias))
+            L.w_fc2, L.b_fc2 = K(self._h16(blk.mlp.fc2.weight)), K(self._f32(blk.mlp.fc2.bias))
+            L.ln1_g, L.ln1_b = K(self._f32(blk.norm1.weight)), K(self._f32(blk.norm1.bias))
+            L.ln2_g, L.ln2_b = K(self._f32(blk.norm2.weight)), K(self._f32(blk.norm2.bias))
+            if self.fold_layernorm:
+                # LayerNorm folded into the consumer GEMM (inference driver, DESIGN.md section 4): W' = h16(gamma * W),
+                # s = row sums of the ROUNDED W', t = W beta + b in fp32
+                wq = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).detach().float()
+                bq = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).detach().float()
+                for tag, w0, b0, nrm in (("qkv", wq, bq, blk.norm1), ("fc1", blk.mlp.fc1.weight.detach().float(),
+                                                                     blk.mlp.fc1.bias.detach().float(), blk.norm2)):
+                    gam, bet = nrm.weight.detach().float(), nrm.bias.detach().float()
+                    wf = self._h16(w0 * gam)
+                    setattr(L, f"w_{tag}_fold", K(wf))
+                    setattr(L, f"{tag}_fold_s", K(wf.float().sum(1).contiguous()))
+                    setattr(L, f"{tag}_fold_t", K((w0.double() @ bet.double() + b0.double()).float().contiguous()))
+            if self.split_last_block and i == len(v.blocks) - 1:
+                L.w_q_split = K(hip.split_pack_weight(a.q_proj.weight, self.prec))
+                L.w_out_split = K(hip.split_pack_weight(a.out_proj.weight, self.prec))
+                L.w_fc1_split = K(hip.split_pack_weight(blk.mlp.fc1.weight, self.prec))
+                L.w_fc2_split = K(hip.split_pack_weight(blk.mlp.fc2.weight, self.prec))
+            L.w_cls, L.b_cls = K(self._h16(blk.cls_proj.weight)), K(self._f32(blk.cls_proj.bias))
+            L.sln_g, L.sln_b = K(self._f32(blk.summary_ln.weight)), K(self._f32(blk.summary_ln.bias))
+            w_sqkv_t.append(self._h16(torch.cat([s.q_proj.weight, s.k_proj.weight, s.v_proj.weight], 0)))
+            w_sout_t.append(self._h16(s.out_proj.weight))
+            L.w_sqkv, L.w_sout = K(w_sqkv_t[-1]), K(w_sout_t[-1])
+            b_sqkv_t.append(self._f32(torch.cat([s.q_proj.bias, s.k_proj.bias, s.v_proj.bias], 0)))
+            L.b_sqkv = K(b_sqkv_t[-1])
+            L.b_sout = K(self._f32(s.out_proj.bias))
+            L.local_prompts = K(self._f32(blk.local_prompts[0]))
+            L.global_prompts = K(self._f32(v.global_prompts[i]))
+        packed.update(vis=vis, vis_layers=layers, w_sqkv=w_sqkv_t, w_sout=w_sout_t, b_sqkv=b_sqkv_t)
+
+    def _pack_text(self, packed, K):
+        sh = self._shape
+        if True:
+            t = self.textual
+            tlayers = (hip.TextLayer * sh["TL"])()
+            tw = (lambda w: hip.split_pack_weight(w, self.prec)) if self.text_split_precision else self._h16
+            for i, blk in enumerate(t.transformer.resblocks):
+                L = tlayers[i]
+                L.w_qkv, L.b_qkv = K(tw(blk.attn.in_proj_weight)), K(self._f32(blk.attn.in_proj_bias))
+                L.w_out, L.b_out = K(tw(blk.attn.out_proj.weight)), K(self._f32(blk.attn.out_proj.bias))
+                L.w_fc, L.b_fc = K(tw(blk.mlp.c_fc.weight)), K(self._f32(blk.mlp.c_fc.bias))
+                L.w_proj, L.b_proj = K(tw(blk.mlp.c_proj.weight)), K(self._f32(blk.mlp.c_proj.bias))
+                L.ln1_g, L.ln1_b = K(self._f32(blk.ln_1.weight)), K(self._f32(blk.ln_1.bias))
+                L.ln2_g, L.ln2_b = K(self._f32(blk.ln_2.weight)), K(self._f32(blk.ln_2.bias))
+            packed.update(txt=dict(token_embedding=K(self._f32(t.token_embedding.weight)),
+                                   positional_embedding=K(self._f32(t.positional_embedding)),
+                                   lnf_g=K(self._f32(t.ln_final.weight)), lnf_b=K(self._f32(t.ln_final.bias)),
+                                   w_tproj=K(tw(t.text_projection.detach().float().t().contiguous()))),
+                          txt_layers=tlayers)
+            if not getattr(self, "use_text_prompt_learning", False):
+                return          # a bare text tower (direct calls only): no prompt learner, no token table
+            dev = t.token_embedding.weight.device
+            tok0 = torch.cat(self.tokenized_prompts).to(device=dev)
+            eot_col = (tok0 == t.vocab_size - 1).nonzero()[:, -1]
+            assert eot_col.numel() == tok0.shape[0], "every prompt must contain exactly one EOT token"
+            # Causal attention: the EOT row - the only one the text features read (text_encoder.py:169) - depends on the
+            # rows up to itself only, and LayerNorm / MLP are row-wise.  Rows behind the last EOT of any prompt are
+            # dead work (the reference pads every prompt to 77): the tower runs on the first L_eff positions, results
+            # identical.  ("X X .. name." prompts: ~15-20 of 77.)
+            L_eff = min(sh["L"], max(int(eot_col.max()) + 1, 1 + sh["n_ctx"]))
+            self.text_rows_per_prompt = L_eff if self.trim_text_rows else sh["L"]
+            L_eff = self.text_rows_per_prompt
+            eot = (torch.arange(tok0.shape[0], device=dev) * L_eff + eot_col).to(torch.int32).contiguous()
+            tok = self.prompt_learner.embedding_token_ids()[:, :L_eff].to(device=dev, dtype=torch.int32).contiguous()
+            packed.update(tokens=tok, eot=eot)
+
+    def _workspace(self, tag, nbytes, device):
+        ws = self._ws.get(tag)
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._ws[tag] = ws
+        return ws
+
+    # ---- encoders -----------------------------------------------------------------------------
+    def encode_video(self, x, saved=None, kept=None):
+        """CLIPVisionEncoder.forward on the HIP path -> (cls_x (B,E), summary (B,D)), fp32.
+        saved: optional fp32 [layers+2, B*T*(n+1), D] that receives what the backward recomputes from;
+        kept: optional dict of per-block activation buffers (training.alloc_kept) filled by gava_vision_forward_keep."""
+        if not x.is_cuda:
+            raise hip.GavaError("VitaCLIP (gava_clip_amd) runs on the HIP device only: move the model and the "
+                                "input with .cuda(); there is no CPU fallback")
+        lib = hip.load()
+        pk, sh = self._pack(), self._shape
+        B, Cc, T, Hh, Ww = x.shape
+        assert Cc == 3 and Hh == sh["size"] and Ww == sh["size"], "input must be (B,3,T,size,size)"
+        x = x.detach().float().contiguous()
+        te = self.visual.time_embed.detach().float()
+        if T != te.size(0):  # VitaCLIP_vision_encoder.py:91-95
+            te = F.interpolate(te.unsqueeze(0).transpose(1, 2), size=(T), mode='nearest').transpose(1, 2).squeeze(0)
+        te = te.contiguous()
+        m = hip.VisionModel()
+        m.B, m.T_in, m.T_model = B, T, self.num_frames
+        for k in ("size", "P", "D", "H", "layers", "F", "E", "G"):
+            setattr(m, k, sh[k])
+        m.prec = self.prec
+        for k, val in pk["vis"].items():
+            setattr(m, k, val)
+        m.time_embed = C.c_void_p(te.data_ptr())
+        m.layer = C.cast(pk["vis_layers"], C.POINTER(hip.VisionLayer))
+        nbytes = lib.gava_vision_workspace_bytes(C.byref(m))
+        if nbytes == 0:
+            raise hip.GavaError(f"unsupported vision shape: B={B} T={T} num_frames={self.num_frames} {sh}")
+        ws = self._workspace("vision", nbytes, x.device)
+        cls_x = torch.empty(B, sh["E"], dtype=torch.float32, device=x.device)
+        summary = torch.empty(B * T // self.num_frames, sh["D"], dtype=torch.float32, device=x.device)
+        dbg = torch.empty(sh["layers"], B * T, sh["D"], dtype=torch.float32, device=x.device) if self.debug_taps else None
+        # the drivers key their side stream by the CURRENT device: make it the input's
+        with torch.cuda.device(x.device):
+            if kept is not None:
+                sv = hip.VisionSaved(hip.ptr(kept["e0"]), hip.ptr(kept["x"]), hip.ptr(kept["x1"]), hip.ptr(kept["qkv"]),
+                                     hip.ptr(kept["pre"]), hip.ptr(kept["sidekv"]), hip.ptr(kept.get("last_q")),
+                                     hip.ptr(kept.get("last_x1")), hip.ptr(kept.get("last_pre")))
+                hip.check(lib.gava_vision_forward_keep(C.byref(m), hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), C.byref(sv),
+                                                       hip.ptr(ws), ws.numel(), hip.stream_ptr(x.device)), "gava_vision_forward_keep")
+            else:
+                hip.check(lib.gava_vision_forward_train(C.byref(m), hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), hip.ptr(dbg),
+                                                        hip.ptr(saved), hip.ptr(ws), ws.numel(), hip.stream_ptr(x.device)),
+                          "gava_vision_forward")
+        self.last["cls_rows"] = dbg
+        return cls_x, summary
+
+    def _text_shard(self, n):
+        """(lo, hi, rows per rank, world) when the prompts are sharded over the ranks, else None (SURVEY.md 8f row 2:
+        every rank would otherwise run the whole text tower redundantly - 2.4 TF per forward at 400 classes)."""
+        import torch.distributed as dist
+        if not (self.shard_text_across_ranks and self.gather_across_ranks and not torch.is_grad_enabled()
+                and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return None
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if n < 2 * world:
+            return None
+        per = (n + world - 1) // world
+        return min(n, rank * per), min(n, (rank + 1) * per), per, world
+
+    def encode_text(self):
+        """prompt_learner() + textual(...) for all classes in one batch -> (C, E) fp32.  With several ranks (eval) each
+        rank encodes a contiguous slice of the prompts and the rows are all-gathered: prompts are independent, so the
+        result is the same as every rank encoding all of them."""
+        pk, sh = self._pack(), self._shape
+        n = pk["tokens"].shape[0]
+        shard = self._text_shard(n)
+        if shard is None:
+            return self._encode_text_rows(0, n)
+        lo, hi, per, world = shard
+        part = torch.zeros(per, sh["E"], dtype=torch.float32, device=pk["tokens"].device)
+        if hi > lo:
+            part[:hi - lo] = self._encode_text_rows(lo, hi)
+        # rank r holds prompts [r*per, (r+1)*per): the rank-major concatenation is already in prompt order, padding last
+        return self._gather(part)[:n].contiguous()
+
+    def _text_model(self, n, L, n_ctx):
+        pk, sh = self._pack(), self._shape
+        m = hip.TextModel()
+        m.n_prompts, m.L, m.W, m.H, m.layers = n, L, sh["W"], sh["TH"], sh["TL"]
+        m.E, m.n_ctx, m.prec = sh["E"], n_ctx, self.prec
+        m.split = int(self.text_split_precision)
+        for k, val in pk["txt"].items():
+            setattr(m, k, val)
+        m.layer = C.cast(pk["txt_layers"], C.POINTER(hip.TextLayer))
+        return m
+
+    def _run_text(self, m, tok, ctx, eot, device):
+        lib = hip.load()
+        nbytes = lib.gava_text_workspace_bytes(C.byref(m))
+        if nbytes == 0:
+            raise hip.GavaError(f"unsupported text shape: n={m.n_prompts} L={m.L} {self._shape}")
+        ws = self._workspace("text", nbytes, device)
+        out = torch.empty(m.n_prompts, self._shape["E"], dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            hip.check(lib.gava_text_forward(C.byref(m), hip.ptr(tok), hip.ptr(ctx), hip.ptr(eot), hip.ptr(out),
+                                            hip.ptr(ws), ws.numel(), hip.stream_ptr(device)), "gava_text_forward")
+        return out
+
+    def _encode_text_rows(self, lo, hi):
+        """The text tower on prompts [lo, hi)."""
+        pk, sh = self._pack(), self._shape
+        L = self.text_rows_per_prompt
+        tok = pk["tokens"][lo:hi].contiguous()
+        ctx = self.prompt_learner.full_context().detach().float()[lo:hi].contiguous()
+        eot = (pk["eot"][lo:hi] - lo * L).to(torch.int32).contiguous()      # flat row index n*L + column, rebased to the slice
+        return self._run_text(self._text_model(tok.shape[0], L, sh["n_ctx"]), tok, ctx, eot, tok.device)
+
+    def encode_prompt_embeddings(self, prompts, tokenized_prompts):
+        """CLIPTextEncoder.forward(prompts, tokenized_prompts) (VitaCLIP_text_encoder.py:154-171) on ready-made prompt
+        embeddings (n, L, W) - the call of evaluation/zero_shot.py:75-76 and utils/prepare_embedding.py - through the
+        HIP text tower's direct mode (no token table, no context splice).  Inference only: training goes through
+        VitaCLIP.forward, whose TextTowerFn owns the backward."""
+        if not prompts.is_cuda:
+            raise hip.GavaError("CLIPTextEncoder (gava_clip_amd) runs on the HIP device only; there is no CPU fallback")
+        if torch.is_grad_enabled() and prompts.requires_grad:
+            raise hip.GavaError("CLIPTextEncoder.forward called stand-alone has no backward: train through VitaCLIP.forward")
+        self._pack()
+        tok = tokenized_prompts.to(prompts.device)
+        n, L, W = prompts.shape
+        assert tuple(tok.shape) == (n, L) and W == self._shape["W"] and L <= self._shape["L"]
+        hit = (tok == self.textual.vocab_size - 1).nonzero()
+        assert hit.shape[0] == n, "every prompt must contain exactly one EOT token"      # text_encoder.py:169
+        eot_col = hit[:, -1]
+        L_eff = int(eot_col.max()) + 1 if self.trim_text_rows else L        # rows behind the last EOT are dead work (causal)
+        x = prompts.detach().float()[:, :L_eff].contiguous()
+        eot = (torch.arange(n, device=tok.device) * L_eff + eot_col).to(torch.int32).contiguous()
+        return self._run_text(self._text_model(n, L_eff, 0), None, x, eot, prompts.device)
+
+
+class _StandaloneHost(_HipHost):
+    """Host of an encoder that was constructed on its own (evaluation/zero_shot.py:42-52 builds a bare CLIPTextEncoder,
+    evaluation/iwa.py a bare CLIPVisionEncoder): packs that encoder's weights and launches its tower."""
+
+    def __init__(self, enc):
+        self._enc = weakref.ref(enc)
+        self.use_text_prompt_learning = False
+        if isinstance(enc, CLIPVisionEncoder):
+            self.num_frames = enc.num_frames
+        self._hip_init(enc._hip_shape)
+
+    def __getattr__(self, name):      # `visual` / `textual` resolve to the encoder without keeping it alive (no cycle)
+        if name in ("visual", "textual"):
+            enc = self.__dict__["_enc"]()
+            if enc is not None and isinstance(enc, CLIPVisionEncoder if name == "visual" else CLIPTextEncoder):
+                return enc
+        raise AttributeError(name)
+
+    def named_parameters(self):
+        return self._enc().named_parameters()
+
+    def parameters(self):
+        return self._enc().parameters()
+
+
 # ---------------------------------------------------------------------------------------------
-class VitaCLIP(nn.Module):
+class VitaCLIP(nn.Module, _HipHost):
 
     def __init__(
         self,
@@ -359,8 +778,11 @@ class VitaCLIP(nn.Module):
         if self.zeroshot_evaluation:
             self.text_features = torch.load(zeroshot_text_features_path, map_location='cpu',
                                             weights_only=True)['text_features']
-        self.visual = CLIPVisionEncoder(input_size, num_frames, feature_dim, patch_size, num_heads, num_layers,
-                                        mlp_factor, embed_dim, num_global_prompts)
+        self.visual = CLIPVisionEncoder(input_size=input_size, num_frames=num_frames, feature_dim=feature_dim,
+                                        patch_size=patch_size, num_heads=num_heads, num_layers=num_layers,
+                                        mlp_factor=mlp_factor, embed_dim=embed_dim, use_summary_token=True,
+                                        use_local_prompts=True, use_global_prompts=True,
+                                        num_global_prompts=num_global_prompts)
         self.use_text_prompt_learning = use_text_prompt_learning
         if self.use_text_prompt_learning:
             self.textual = CLIPTextEncoder(embed_dim, text_context_length, text_vocab_size, text_transformer_width,
@@ -409,300 +831,17 @@ class VitaCLIP(nn.Module):
                 param[1].requires_grad = False
 
         # ---- HIP-path state (not part of the reference surface)
-        operand_dtype = operand_dtype or os.environ.get("GAVA_PREC", "fp16")
-        self.prec = hip.PREC_NAMES[operand_dtype]
-        # text tower GEMMs in split precision (hi+lo operands, 3 MFMA passes): the text side is <1 % of
-        # the work at the headline configs but dominates the logits error at plain 16-bit operands
-        self.text_split_precision = os.environ.get("GAVA_TEXT_SPLIT", "1") != "0"
-        # eval-time text-feature cache: in eval mode the text tower is input
-        # independent; opt-in because a benchmark must not skip work.  Invalidated by any parameter update.
-        self.cache_text_features = False
-        self.text_on_side_stream = os.environ.get("GAVA_TEXT_STREAM", "1") != "0"
-        # inference: LayerNorm folded into the qkv / fc1 GEMMs (two row passes per block less); GAVA_LN_FOLD=0 turns it off
-        self.fold_layernorm = os.environ.get("GAVA_LN_FOLD", "1") != "0"
-        self.trim_text_rows = os.environ.get("GAVA_TEXT_TRIM", "1") != "0"   # skip the rows behind the last EOT (see _pack)
-        self.text_rows_per_prompt = text_context_length
-        # training: keep the backward's activations (~21 GB at B = 64, T = 8) instead of recomputing them per block, as
-        # long as they fit this budget; beyond it the backward recomputes from the block inputs only
-        self.keep_activation_bytes = int(float(os.environ.get("GAVA_KEEP_ACT_GB", "96")) * 2 ** 30)
-        self._text_stream = None
-        self._text_cache = None
-        self.gather_across_ranks = True     # RCCL all-gather of clip embeddings when world_size > 1
-        self.shard_text_across_ranks = True  # eval, world_size > 1: each rank encodes a slice of the prompts (+ all-gather)
-        self.debug_taps = False             # keep per-layer CLS rows of the last forward
-        self._shape = dict(size=input_size[0], P=patch_size[0], D=feature_dim, H=num_heads, layers=num_layers,
-                           F=round(mlp_factor * feature_dim), E=embed_dim, G=num_global_prompts,
-                           W=text_transformer_width, TH=text_transformer_heads, TL=text_transformer_layers,
-                           L=text_context_length, n_ctx=text_num_prompts)
-        self._packed = None
-        self._packed_key = None
-        self._ws = {}
-        self.last = {}
+        self._hip_init(dict(size=input_size[0], P=patch_size[0], D=feature_dim, H=num_heads, layers=num_layers,
+                            F=round(mlp_factor * feature_dim), E=embed_dim, G=num_global_prompts,
+                            W=text_transformer_width, TH=text_transformer_heads, TL=text_transformer_layers,
+                            L=text_context_length, n_ctx=text_num_prompts), operand_dtype)
+        self._attach_encoders()
 
-    # ---- weight packing -----------------------------------------------------------------------
-    def set_operand_dtype(self, name: str):
-        self.prec = hip.PREC_NAMES[name]
-        self._packed = None
-
-    _PASS_THROUGH = ("prompt_learner.", "logit_scale", "global_prompts", "local_prompts", "token_embedding",
-                     "pos_embed", "time_embed", "positional_embedding", "cls_token", "sum_proj", "tf_project",
-                     "memory_project")
-
-    def _pack_key(self):
-        """Changes when a packed 16-bit copy goes stale.  fp32 pass-through parameters (prompts, embeddings, LN
-        affines, biases: the structs hold pointers into their own storage) only count by address, so an optimizer
-        step on the prompt parameters does not re-convert 180 M frozen weights."""
-        ver, addr = 0, 0
-        for name, p in self.named_parameters():
-            addr ^= p.data_ptr()
-            if p.dim() >= 2 and not p.requires_grad and not any(k in name for k in self._PASS_THROUGH):
-                ver += p._version
-        if self.fold_layernorm:   # norm1 / norm2 affines and the qkv / fc1 biases are baked into the folded copies
-            for blk in self.visual.blocks:
-                for q in (blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias, blk.attn.q_proj.bias,
-                          blk.attn.k_proj.bias, blk.attn.v_proj.bias, blk.mlp.fc1.bias):
-                    ver += q._version
-        ps = next(self.parameters())
-        return (self.prec, self.text_split_precision, self.trim_text_rows, self.fold_layernorm, ps.device, addr, ver)
-
-    def _summary_weight_versions(self):
-        """Versions of the only TRAINABLE weights that have 16-bit copies (summary_attn_layer projections): an optimizer
-        step refreshes just those copies in place (same device pointers) instead of re-converting every frozen weight."""
-        return [tuple(w._version for w in (b.summary_attn_layer.q_proj.weight, b.summary_attn_layer.k_proj.weight,
-                                           b.summary_attn_layer.v_proj.weight, b.summary_attn_layer.out_proj.weight,
-                                           b.summary_attn_layer.q_proj.bias, b.summary_attn_layer.k_proj.bias,
-                                           b.summary_attn_layer.v_proj.bias))
-                for b in self.visual.blocks]
-
-    def _refresh_summary_weights(self, packed):
-        cur = self._summary_weight_versions()
-        if cur == packed["summary_ver"]:
-            return
-        for i, blk in enumerate(self.visual.blocks):
-            if cur[i] != packed["summary_ver"][i]:
-                s_ = blk.summary_attn_layer
-                packed["w_sqkv"][i].copy_(self._h16(torch.cat([s_.q_proj.weight, s_.k_proj.weight, s_.v_proj.weight], 0)))
-                packed["w_sout"][i].copy_(self._h16(s_.out_proj.weight))
-                packed["b_sqkv"][i].copy_(torch.cat([s_.q_proj.bias, s_.k_proj.bias, s_.v_proj.bias], 0).detach().float())
-        packed["summary_ver"] = cur
-
-    def _pack_vision_backward(self):
-        from . import training
-        key = self._pack_key()
-        if getattr(self, "_bwd_pack_v", None) is None or self._bwd_pack_v[0] != key:
-            self._bwd_pack_v = (key, training.pack_vision_backward(self))
-        training.refresh_vision_backward(self, self._bwd_pack_v[1])
-        return self._bwd_pack_v[1]
-
-    def _pack_text_backward(self):
-        from . import training
-        key = self._pack_key()
-        if getattr(self, "_bwd_pack", None) is None or self._bwd_pack[0] != key:
-            self._bwd_pack = (key, training.pack_text_backward(self))
-        return self._bwd_pack[1]
-
-    def _h16(self, t):
-        return hip.convert_h16(t.detach().float(), self.prec)
-
-    def _f32(self, t):
-        return t.detach().float().contiguous()
-
-    def _pack(self):
-        key = self._pack_key()
-        if self._packed is not None and self._packed_key == key:
-            self._refresh_summary_weights(self._packed)
-            return self._packed
-        sh, v = self._shape, self.visual
-        keep = []  # tensors referenced by raw pointers in the structs
-        w_sqkv_t, w_sout_t, b_sqkv_t = [], [], []
-
-        def K(t):
-            keep.append(t)
-            return C.c_void_p(t.data_ptr())
-
-        Kp = (3 * sh["P"] ** 2 + 63) // 64 * 64
-        wpatch = v.patch_embed.proj.weight.detach().float().reshape(sh["D"], -1)
-        if Kp != wpatch.shape[1]:
-            wpatch = F.pad(wpatch, (0, Kp - wpatch.shape[1]))
-        vis = dict(w_patch=K(self._h16(wpatch)), b_patch=K(self._f32(v.patch_embed.proj.bias)),
-                   cls_token=K(self._f32(v.cls_token)), pos_embed=K(self._f32(v.pos_embed)),
-                   lnpre_g=K(self._f32(v.ln_pre.weight)), lnpre_b=K(self._f32(v.ln_pre.bias)),
-                   lnpost_g=K(self._f32(v.ln_post.weight)), lnpost_b=K(self._f32(v.ln_post.bias)),
-                   w_proj=K(hip.split_pack_weight(v.proj.detach().float().t(), self.prec)))
-        layers = (hip.VisionLayer * sh["layers"])()
-        for i, blk in enumerate(v.blocks):
-            a, s = blk.attn, blk.summary_attn_layer
-            L = layers[i]
-            L.w_qkv = K(self._h16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)))
-            L.b_qkv = K(self._f32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)))
-            L.w_out, L.b_out = K(self._h16(a.out_proj.weight)), K(self._f32(a.out_proj.bias))
-            L.w_fc1, L.b_fc1 = K(self._h16(blk.mlp.fc1.weight)), K(self._f32(blk.mlp.fc1.bias))
-            L.w_fc2, L.b_fc2 = K(self._h16(blk.mlp.fc2.weight)), K(self._f32(blk.mlp.fc2.bias))
-            L.ln1_g, L.ln1_b = K(self._f32(blk.norm1.weight)), K(self._f32(blk.norm1.bias))
-            L.ln2_g, L.ln2_b = K(self._f32(blk.norm2.weight)), K(self._f32(blk.norm2.bias))
-            if self.fold_layernorm:
-                # LayerNorm folded into the consumer GEMM (inference driver, DESIGN.md section 4): W' = h16(gamma * W),
-                # s = row sums of the ROUNDED W', t = W beta + b in fp32
-                wq = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).detach().float()
-                bq = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).detach().float()
-                for tag, w0, b0, nrm in (("qkv", wq, bq, blk.norm1), ("fc1", blk.mlp.fc1.weight.detach().float(),
-                                                                     blk.mlp.fc1.bias.detach().float(), blk.norm2)):
-                    gam, bet = nrm.weight.detach().float(), nrm.bias.detach().float()
-                    wf = self._h16(w0 * gam)
-                    setattr(L, f"w_{tag}_fold", K(wf))
-                    setattr(L, f"{tag}_fold_s", K(wf.float().sum(1).contiguous()))
-                    setattr(L, f"{tag}_fold_t", K((w0.double() @ bet.double() + b0.double()).float().contiguous()))
-            L.w_cls, L.b_cls = K(self._h16(blk.cls_proj.weight)), K(self._f32(blk.cls_proj.bias))
-            L.sln_g, L.sln_b = K(self._f32(blk.summary_ln.weight)), K(self._f32(blk.summary_ln.bias))
-            w_sqkv_t.append(self._h16(torch.cat([s.q_proj.weight, s.k_proj.weight, s.v_proj.weight], 0)))
-            w_sout_t.append(self._h16(s.out_proj.weight))
-            L.w_sqkv, L.w_sout = K(w_sqkv_t[-1]), K(w_sout_t[-1])
-            b_sqkv_t.append(self._f32(torch.cat([s.q_proj.bias, s.k_proj.bias, s.v_proj.bias], 0)))
-            L.b_sqkv = K(b_sqkv_t[-1])
-            L.b_sout = K(self._f32(s.out_proj.bias))
-            L.local_prompts = K(self._f32(blk.local_prompts[0]))
-            L.global_prompts = K(self._f32(v.global_prompts[i]))
-        packed = dict(vis=vis, vis_layers=layers, keep=keep, w_sqkv=w_sqkv_t, w_sout=w_sout_t, b_sqkv=b_sqkv_t,
-                      summary_ver=self._summary_weight_versions())
-        if self.use_text_prompt_learning:
-            t = self.textual
-            tlayers = (hip.TextLayer * sh["TL"])()
-            tw = (lambda w: hip.split_pack_weight(w, self.prec)) if self.text_split_precision else self._h16
-            for i, blk in enumerate(t.transformer.resblocks):
-                L = tlayers[i]
-                L.w_qkv, L.b_qkv = K(tw(blk.attn.in_proj_weight)), K(self._f32(blk.attn.in_proj_bias))
-                L.w_out, L.b_out = K(tw(blk.attn.out_proj.weight)), K(self._f32(blk.attn.out_proj.bias))
-                L.w_fc, L.b_fc = K(tw(blk.mlp.c_fc.weight)), K(self._f32(blk.mlp.c_fc.bias))
-                L.w_proj, L.b_proj = K(tw(blk.mlp.c_proj.weight)), K(self._f32(blk.mlp.c_proj.bias))
-                L.ln1_g, L.ln1_b = K(self._f32(blk.ln_1.weight)), K(self._f32(blk.ln_1.bias))
-                L.ln2_g, L.ln2_b = K(self._f32(blk.ln_2.weight)), K(self._f32(blk.ln_2.bias))
-            dev = t.token_embedding.weight.device
-            tok0 = torch.cat(self.tokenized_prompts).to(device=dev)
-            eot_col = (tok0 == t.vocab_size - 1).nonzero()[:, -1]
-            assert eot_col.numel() == tok0.shape[0], "every prompt must contain exactly one EOT token"
-            # Causal attention: the EOT row - the only one the text features read (text_encoder.py:169) - depends on the
-            # rows up to itself only, and LayerNorm / MLP are row-wise.  Rows behind the last EOT of any prompt are
-            # dead work (the reference pads every prompt to 77): the tower runs on the first L_eff positions, results
-            # identical.  ("X X .. name." prompts: ~15-20 of 77.)
-            L_eff = min(sh["L"], max(int(eot_col.max()) + 1, 1 + sh["n_ctx"]))
-            self.text_rows_per_prompt = L_eff if self.trim_text_rows else sh["L"]
-            L_eff = self.text_rows_per_prompt
-            eot = (torch.arange(tok0.shape[0], device=dev) * L_eff + eot_col).to(torch.int32).contiguous()
-            tok = self.prompt_learner.embedding_token_ids()[:, :L_eff].to(device=dev, dtype=torch.int32).contiguous()
-            packed.update(txt=dict(token_embedding=K(self._f32(t.token_embedding.weight)),
-                                   positional_embedding=K(self._f32(t.positional_embedding)),
-                                   lnf_g=K(self._f32(t.ln_final.weight)), lnf_b=K(self._f32(t.ln_final.bias)),
-                                   w_tproj=K(tw(t.text_projection.detach().float().t().contiguous()))),
-                          txt_layers=tlayers, tokens=tok, eot=eot)
-        self._packed, self._packed_key = packed, key
-        return packed
-
-    def _workspace(self, tag, nbytes, device):
-        ws = self._ws.get(tag)
-        if ws is None or ws.numel() < nbytes or ws.device != device:
-            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-            self._ws[tag] = ws
-        return ws
-
-    # ---- encoders -----------------------------------------------------------------------------
-    def encode_video(self, x, saved=None, kept=None):
-        """CLIPVisionEncoder.forward on the HIP path -> (cls_x (B,E), summary (B,D)), fp32.
-        saved: optional fp32 [layers+2, B*T*(n+1), D] that receives what the backward recomputes from;
-        kept: optional dict of per-block activation buffers (training.alloc_kept) filled by gava_vision_forward_keep."""
-        if not x.is_cuda:
-            raise hip.GavaError("VitaCLIP (gava_clip_amd) runs on the HIP device only: move the model and the "
-                                "input with .cuda(); there is no CPU fallback")
-        lib = hip.load()
-        pk, sh = self._pack(), self._shape
-        B, Cc, T, Hh, Ww = x.shape
-        assert Cc == 3 and Hh == sh["size"] and Ww == sh["size"], "input must be (B,3,T,size,size)"
-        x = x.detach().float().contiguous()
-        te = self.visual.time_embed.detach().float()
-        if T != te.size(0):  # VitaCLIP_vision_encoder.py:91-95
-            te = F.interpolate(te.unsqueeze(0).transpose(1, 2), size=(T), mode='nearest').transpose(1, 2).squeeze(0)
-        te = te.contiguous()
-        m = hip.VisionModel()
-        m.B, m.T_in, m.T_model = B, T, self.num_frames
-        for k in ("size", "P", "D", "H", "layers", "F", "E", "G"):
-            setattr(m, k, sh[k])
-        m.prec = self.prec
-        for k, val in pk["vis"].items():
-            setattr(m, k, val)
-        m.time_embed = C.c_void_p(te.data_ptr())
-        m.layer = C.cast(pk["vis_layers"], C.POINTER(hip.VisionLayer))
-        nbytes = lib.gava_vision_workspace_bytes(C.byref(m))
-        if nbytes == 0:
-            raise hip.GavaError(f"unsupported vision shape: B={B} T={T} num_frames={self.num_frames} {sh}")
-        ws = self._workspace("vision", nbytes, x.device)
-        cls_x = torch.empty(B, sh["E"], dtype=torch.float32, device=x.device)
-        summary = torch.empty(B * T // self.num_frames, sh["D"], dtype=torch.float32, device=x.device)
-        dbg = torch.empty(sh["layers"], B * T, sh["D"], dtype=torch.float32, device=x.device) if self.debug_taps else None
-        if kept is not None:
-            sv = hip.VisionSaved(hip.ptr(kept["e0"]), hip.ptr(kept["x"]), hip.ptr(kept["x1"]), hip.ptr(kept["qkv"]),
-                                 hip.ptr(kept["pre"]), hip.ptr(kept["sidekv"]), hip.ptr(kept.get("last_q")),
-                                 hip.ptr(kept.get("last_x1")), hip.ptr(kept.get("last_pre")))
-            hip.check(lib.gava_vision_forward_keep(C.byref(m), hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), C.byref(sv),
-                                                   hip.ptr(ws), ws.numel(), hip.stream_ptr()), "gava_vision_forward_keep")
-        else:
-            hip.check(lib.gava_vision_forward_train(C.byref(m), hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), hip.ptr(dbg),
-                                                    hip.ptr(saved), hip.ptr(ws), ws.numel(), hip.stream_ptr()),
-                      "gava_vision_forward")
-        self.last["cls_rows"] = dbg
-        return cls_x, summary
-
-    def _text_shard(self, n):
-        """(lo, hi, rows per rank, world) when the prompts are sharded over the ranks, else None (SURVEY.md 8f row 2:
-        every rank would otherwise run the whole text tower redundantly - 2.4 TF per forward at 400 classes)."""
-        import torch.distributed as dist
-        if not (self.shard_text_across_ranks and self.gather_across_ranks and not torch.is_grad_enabled()
-                and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-            return None
-        world, rank = dist.get_world_size(), dist.get_rank()
-        if n < 2 * world:
-            return None
-        per = (n + world - 1) // world
-        return min(n, rank * per), min(n, (rank + 1) * per), per, world
-
-    def encode_text(self):
-        """prompt_learner() + textual(...) for all classes in one batch -> (C, E) fp32.  With several ranks (eval) each
-        rank encodes a contiguous slice of the prompts and the rows are all-gathered: prompts are independent, so the
-        result is the same as every rank encoding all of them."""
-        pk, sh = self._pack(), self._shape
-        n = pk["tokens"].shape[0]
-        shard = self._text_shard(n)
-        if shard is None:
-            return self._encode_text_rows(0, n)
-        lo, hi, per, world = shard
-        part = torch.zeros(per, sh["E"], dtype=torch.float32, device=pk["tokens"].device)
-        if hi > lo:
-            part[:hi - lo] = self._encode_text_rows(lo, hi)
-        # rank r holds prompts [r*per, (r+1)*per): the rank-major concatenation is already in prompt order, padding last
-        return self._gather(part)[:n].contiguous()
-
-    def _encode_text_rows(self, lo, hi):
-        """The text tower on prompts [lo, hi)."""
-        lib = hip.load()
-        pk, sh = self._pack(), self._shape
-        L = self.text_rows_per_prompt
-        tok = pk["tokens"][lo:hi].contiguous()
-        n = tok.shape[0]
-        m = hip.TextModel()
-        m.n_prompts, m.L, m.W, m.H, m.layers = n, self.text_rows_per_prompt, sh["W"], sh["TH"], sh["TL"]
-        m.E, m.n_ctx, m.prec = sh["E"], sh["n_ctx"], self.prec
-        m.split = int(self.text_split_precision)
-        for k, val in pk["txt"].items():
-            setattr(m, k, val)
-        m.layer = C.cast(pk["txt_layers"], C.POINTER(hip.TextLayer))
-        nbytes = lib.gava_text_workspace_bytes(C.byref(m))
-        if nbytes == 0:
-            raise hip.GavaError(f"unsupported text shape: {sh}")
-        ws = self._workspace("text", nbytes, tok.device)
-        ctx = self.prompt_learner.full_context().detach().float()[lo:hi].contiguous()
-        eot = (pk["eot"][lo:hi] - lo * L).to(torch.int32).contiguous()      # flat row index n*L + column, rebased to the slice
-        out = torch.empty(n, sh["E"], dtype=torch.float32, device=tok.device)
-        hip.check(lib.gava_text_forward(C.byref(m), hip.ptr(tok), hip.ptr(ctx), hip.ptr(eot), hip.ptr(out),
-                                        hip.ptr(ws), ws.numel(), hip.stream_ptr()), "gava_text_forward")
-        return out
+    def _attach_encoders(self):
+        """The L1 encoders stay callable on their own (evaluation/iwa.py:212, zero_shot.py:75): they run on this host."""
+        self.visual.__dict__["_host_ref"] = weakref.ref(self)
+        if hasattr(self, "textual"):
+            self.textual.__dict__["_host_ref"] = weakref.ref(self)
 
     def _gather(self, feats):
         """RCCL all-gather over xGMI of the per-clip embeddings (north_star): each rank
@@ -757,6 +896,15 @@ class VitaCLIP(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, memory=None, video_nte=None, desc_wise=False):
+        if not x.is_cuda:
+            raise hip.GavaError("VitaCLIP (gava_clip_amd) runs on the HIP device only: move the model and the "
+                                "input with .cuda(); there is no CPU fallback")
+        # every launch below names "the current stream": make the input's device the current one (a model on cuda:k
+        # called without torch.cuda.set_device(k) would otherwise launch on another device's stream)
+        with torch.cuda.device(x.device):
+            return self._forward_impl(x, memory, video_nte, desc_wise)
+
+    def _forward_impl(self, x, memory, video_nte, desc_wise):
         lib = hip.load()
         B, Cc, T, Hh, Ww = x.size()
         sh = self._shape
@@ -764,6 +912,7 @@ class VitaCLIP(nn.Module):
             raise hip.GavaError("VitaCLIP (gava_clip_amd) runs on the HIP device only: move the model and the "
                                 "input with .cuda(); there is no CPU fallback")
         text, text_stream = None, None
+        self._attach_encoders()
         self._pack()   # (re)pack weights on the caller's stream, before any fork
         if self.use_text_prompt_learning:
             if desc_wise:
@@ -837,7 +986,7 @@ class VitaCLIP(nn.Module):
             ls = self.logit_scale.detach().float().reshape(1)
             lb = self.logit_bias.detach().float().reshape(1) if self.logit_bias is not None else None
             hip.check(lib.gava_similarity_head(hip.ptr(video), hip.ptr(text), hip.ptr(ls), hip.ptr(lb), Bg, n_cls, n_kv,
-                                               sh["E"], hip.ptr(logits), hip.ptr(tfeat), hip.ptr(vnorm), hip.stream_ptr()),
+                                               sh["E"], hip.ptr(logits), hip.ptr(tfeat), hip.ptr(vnorm), hip.stream_ptr(x.device)),
                       "gava_similarity_head")
             self.last.update(video_features=vnorm, summary=summary)
             if desc_wise and self.use_text_prompt_learning:

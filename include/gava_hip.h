@@ -92,6 +92,10 @@ typedef struct {
    * fold_t[n] = sum_k beta[k] * W0[n][k] + bias[n] (bias must then be NULL). */
   void* x16_out; int64_t ld_x16; float* rowsum_out;
   const float* fold_stats; const float* fold_s; const float* fold_t;
+  /* persistent (one workgroup per CU) kernels only: leave this many CUs out of the grid, so that small kernels the
+   * caller runs on another stream beside this GEMM get CUs of their own (0 = use every CU).  Per call: the library keeps
+   * no launch state between calls. */
+  int cu_reserve;
 } gava_gemm_args;
 int gava_gemm(const gava_gemm_args* a, gava_stream_t stream);
 
@@ -154,6 +158,12 @@ typedef struct {                 /* one TransformerEncoderLayer, utils:93-203 */
    * *_fold_t[n] = sum_k beta[k] * W[n][k] + bias[n] in fp32.  qkv: norm1 of this block, fc1: norm2. */
   const void* w_qkv_fold; const float* qkv_fold_s; const float* qkv_fold_t;
   const void* w_fc1_fold; const float* fc1_fold_s; const float* fc1_fold_t;
+  /* Optional (all NULL = off), read for the LAST block of the inference driver only: its B*T CLS rows - the only rows
+   * of that block that reach the outputs (VitaCLIP_vision_encoder.py:126) - run q_proj, out_proj, fc1 and fc2 in split
+   * precision (weights packed [W_hi | W_hi | W_lo], see gava_gemm_args.split_out): 1/197 of the block's rows, and their
+   * rounding lands on the video feature directly.  w_q_split [D][3D], w_out_split [D][3D], w_fc1_split [F][3D],
+   * w_fc2_split [D][3F]. */
+  const void* w_q_split; const void* w_out_split; const void* w_fc1_split; const void* w_fc2_split;
 } gava_vision_layer;
 
 typedef struct {
@@ -200,7 +210,10 @@ typedef struct {
  * (VitaCLIP_text_encoder.py:310-332,154-171; the per-class Python loop of
  * VitaCLIP_model.py:282-285).  tokens: int32 [n_prompts][L]; ctx: fp32 [n_prompts][n_ctx][W];
  * eot_index: int32 [n_prompts], FLAT row n*L + column of the token vocab-1 (text_encoder.py:169).
- * out: fp32 [n_prompts][E]. */
+ * out: fp32 [n_prompts][E].
+ * tokens == NULL: direct mode = CLIPTextEncoder.forward(prompts, tokenized_prompts) called on ready-made prompt
+ * embeddings (evaluation/zero_shot.py:75-76, utils/prepare_embedding.py): ctx is then fp32 [n_prompts][L][W], the
+ * whole `prompts` argument; n_ctx is ignored. */
 size_t gava_text_workspace_bytes(const gava_text_model* m);
 int gava_text_forward(const gava_text_model* m, const int32_t* tokens, const float* ctx,
                       const int32_t* eot_index, float* out, void* workspace,

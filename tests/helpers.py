@@ -33,3 +33,24 @@ def synth_torch_state(cfg, n_cls, seed=0):
 def rel_to_max(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+# The parity criterion of the logits (SURVEY.md 8d "max abs(d)/abs(ref), threshold 1e-3", north_star "within 1e-3
+# relative"), written as a mixed bound so that it is defined for a logit near zero: every element must satisfy
+#     |got - ref| <= RTOL * |ref| + ATOL,   RTOL = 1e-3,  ATOL = 5e-4
+# ATOL is 3e-4 of the largest c1 logit (1.6), the size of the path's absolute error with fp16 operands (measured
+# max |d| = 4.7e-4 ... 5.2e-4 on logits of 0.12 ... 1.6): the error of a logit does not shrink with the logit (it is a
+# dot product of two unit vectors whose components each carry ~3e-4 of rounding), so the PURE element-wise ratio on the
+# smallest c1 logit (0.12) lands anywhere between 1.3e-3 and 4.2e-3 as roundings elsewhere change.
+LOGITS_RTOL, LOGITS_ATOL = 1e-3, 5e-4
+
+
+def mixed_violation(got, ref, rtol=LOGITS_RTOL, atol=LOGITS_ATOL):
+    """max over elements of |got - ref| / (rtol * |ref| + atol): <= 1 means the mixed criterion holds."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float((np.abs(got - ref) / (rtol * np.abs(ref) + atol)).max())
+
+
+def elementwise_rel(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float((np.abs(got - ref) / np.abs(ref)).max())

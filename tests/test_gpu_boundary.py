@@ -1,0 +1,172 @@
+"""GPU: branches of the drop-in boundary beyond the plain prompt-learning forward, each against a fixture the REFERENCE
+produced in the build container (tools/gen_golden.py --round2): the zero-shot branch, the sigmoid-loss head
+(learnable logit_bias), knowledge-aware prompts whose EOT sits inside the context slots, the L1 encoder interface
+(`model.visual(x)`, `model.textual(prompts, tokenized)`, evaluation/iwa.py:212,230, evaluation/zero_shot.py:75-76) and the
+`torch.autocast` caller of training/train.py:441."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gava_clip_amd import VitaCLIP, synth, hip  # noqa: E402
+from gava_clip_amd.config import TINY  # noqa: E402
+from helpers import CLASSES_3, model_kwargs, synth_torch_state, rel_to_max  # noqa: E402
+
+
+def _x(B=2):
+    return torch.from_numpy(synth.synth_clip(B, TINY.num_frames, TINY.input_size)).cuda()
+
+
+def test_zeroshot_branch_matches_reference(golden_dir, tmp_path):
+    """VitaCLIP_model.py:97-98,295-306: use_text_prompt_learning=False, class features from a checkpoint file; no text
+    tower is built and the state_dict has no textual / prompt_learner keys."""
+    g = np.load(os.path.join(golden_dir, "tiny_zeroshot.npz"))
+    path = str(tmp_path / "tf.pth")
+    torch.save({"text_features": torch.from_numpy(g["text_features_in"])}, path)
+    kw = {**model_kwargs(TINY, CLASSES_3), "use_text_prompt_learning": False, "zeroshot_evaluation": True,
+          "zeroshot_text_features_path": path}
+    m = VitaCLIP(**kw)
+    assert sorted(m.state_dict().keys()) == sorted(g["state_keys"].tolist())
+    sd = synth_torch_state(TINY, 3)
+    m.load_state_dict({k: sd[k] for k in m.state_dict().keys()}, strict=True)
+    m = m.cuda().eval()
+    assert not hasattr(m, "textual") and not hasattr(m, "prompt_learner")
+    with torch.no_grad():
+        logits, lmt, lvm = m(_x())
+    assert lmt is None and lvm is None
+    e = rel_to_max(logits.cpu().numpy(), g["logits"])
+    print(f"\n[zero-shot] logits rel-to-max {e:.3e}")
+    assert e < 1e-3
+    # the text features are an input here and stay what the caller loaded (the reference only normalises a local copy)
+    assert torch.equal(m.text_features.cpu(), torch.from_numpy(g["text_features_in"]))
+
+
+def test_visual_submodule_is_callable_like_the_reference(golden_dir, tmp_path):
+    """`model.visual(x)` -> (cls_x (B,E), summary (B,D)) (VitaCLIP_vision_encoder.py:102-132), the call of
+    evaluation/iwa.py:212,230; runs the same HIP tower as the model's forward."""
+    g = np.load(os.path.join(golden_dir, "tiny_zeroshot.npz"))
+    m = VitaCLIP(**model_kwargs(TINY, CLASSES_3))
+    m.load_state_dict(synth_torch_state(TINY, 3), strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        cls_x, summary = m.visual(_x())
+    assert rel_to_max(cls_x.cpu().numpy(), g["visual_cls_x"]) < 2e-3
+    assert rel_to_max(summary.cpu().numpy(), g["visual_summary"]) < 2e-3
+    with pytest.raises(hip.GavaError):
+        m.visual(_x().cpu())
+
+
+def test_sigmoid_loss_head_and_direct_text_tower_match_reference(golden_dir):
+    """use_sigmoid_loss=True: logit_scale / logit_bias of VitaCLIP_model.py:193-197 reach the logits (:308-309) in eval
+    (HIP head) and in training (autograd head, gradients of both scalars); `model.textual(prompts, tokenized)` on raw token
+    embeddings is the call of evaluation/zero_shot.py:75-76."""
+    g = np.load(os.path.join(golden_dir, "tiny_sigmoid.npz"))
+    m = VitaCLIP(**{**model_kwargs(TINY, CLASSES_3), "use_sigmoid_loss": True})
+    sd = synth_torch_state(TINY, 3)
+    sd["logit_scale"] = torch.tensor(float(g["logit_scale"]))
+    sd["logit_bias"] = torch.tensor(float(g["logit_bias"]))
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    x = _x()
+    with torch.no_grad():
+        logits = m(x)[0]
+        tok = torch.cat(m.tokenized_prompts).cuda()
+        direct = m.textual(m.textual.token_embedding(tok), tok)
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() <= 1e-3 * np.abs(g["logits"] - float(g["logit_bias"])).max()
+    assert tuple(direct.shape) == g["textual_direct"].shape
+    assert rel_to_max(direct.cpu().numpy(), g["textual_direct"]) < 2e-3
+    m.train()
+    lg = m(x)[0]
+    (lg * torch.from_numpy(g["w_logits"]).cuda()).sum().backward()
+    got = dict(m.named_parameters())
+    for k in ("logit_scale", "logit_bias", "prompt_learner.ctx", "visual.global_prompts"):
+        r = torch.from_numpy(g["grad." + k]).float()
+        e = float((got[k].grad.float().cpu() - r).norm() / r.norm())
+        assert e < 4e-2, (k, e)
+
+
+def test_kapt_without_descriptions_eot_inside_context_slots(golden_dir, tmp_path, monkeypatch):
+    """text_prompt_init='cntn_split_uni' (no `disc`): the tokenised text is just the class name, so the EOT column
+    (looked up with the UN-shifted ids, text_encoder.py:169) lies inside the context slots and the trimmed text length
+    is n_ctx + 1 - the case the text driver used to reject.  Logits, class features, per-description logits and all
+    gradients against the reference's fixture."""
+    gold = np.load(os.path.join(golden_dir, "tiny_kapt_nodisc.npz"))
+    synth.synth_knowledge_files(str(tmp_path), "updrs", 3, ["v1", "v2", "v3"])
+    monkeypatch.chdir(tmp_path)
+    m = VitaCLIP(**{**model_kwargs(TINY, CLASSES_3), "text_prompt_init": "cntn_split_uni", "knowledge_version": ["v1", "v2", "v3"]})
+    sd = synth_torch_state(TINY, 3)
+    sd.update({k: torch.from_numpy(v) for k, v in synth.synth_kapt_state(TINY, 3).items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    assert np.array_equal(torch.cat(m.tokenized_prompts).numpy(), gold["tokens"])
+    eot_cols = (torch.cat(m.tokenized_prompts) == 49407).nonzero()[:, -1]
+    assert int(eot_cols.max()) <= TINY.text_num_prompts          # the shape of the bug
+    x = _x()
+    for trim in (True, False):
+        m.trim_text_rows = trim
+        with torch.no_grad():
+            logits = m(x)[0]
+            tfeat = m.text_features.clone()
+            desc = m(x, desc_wise=True)[0]
+        assert m.text_rows_per_prompt == (TINY.text_num_prompts + 1 if trim else 77)
+        for got, key in ((logits, "logits"), (tfeat, "text_features"), (torch.stack(desc), "desc_logits")):
+            ref = torch.from_numpy(gold[key])
+            assert got.shape == ref.shape, key
+            assert (got.cpu() - ref).abs().max() <= 1e-3 * ref.abs().max(), (key, trim)
+    m.trim_text_rows = True
+    m.train()
+    lg = m(x)[0]
+    (lg * torch.from_numpy(gold["w_logits"]).cuda()).sum().backward()
+    from test_gpu_backward import _check_against_reference_grads
+    worst = _check_against_reference_grads(m, gold)
+    assert any("context_prompt_learner.projector" in k for k in worst)
+
+
+def test_forward_under_autocast_like_train_py(golden_dir):
+    """training/train.py:441 wraps the forward in torch.cuda.amp.autocast(args.fp16).  The HIP towers ignore autocast
+    (their operand type is the model's own); the torch-traced similarity head of the training path then runs in fp16
+    like the reference's.  The reference's CUDA-autocast numbers cannot be produced in the build container (no GPU):
+    parity of this mode is unpinned - the check is that the call works, returns what the reference's dtype rules give
+    and stays within fp16 rounding of the fp32 golden logits."""
+    g = np.load(os.path.join(golden_dir, "tiny.npz"))
+    m = VitaCLIP(**{**model_kwargs(TINY, CLASSES_3), "use_fp16": True})
+    m.load_state_dict(synth_torch_state(TINY, 3), strict=True)
+    m = m.cuda().train()
+    x = _x()
+    with torch.autocast("cuda", dtype=torch.float16):
+        logits = m(x)[0]
+        loss = torch.nn.functional.cross_entropy(logits, torch.tensor([0, 2], device="cuda"))
+    assert logits.dtype == torch.float16
+    assert rel_to_max(logits.float().detach().cpu().numpy(), g["logits"]) < 4e-3
+    # GradScaler protocol of train.py:358,487-490: the fp16 head overflows at the initial scale of 65536 (as the reference's
+    # fp16 matmul does), the step is skipped and the scale backs off until the gradients are finite
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.0)
+    scaler = torch.amp.GradScaler("cuda")
+    for it in range(8):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = torch.nn.functional.cross_entropy(m(x)[0], torch.tensor([0, 2], device="cuda"))
+        scaler.scale(loss).backward()
+        assert all(p.grad is not None for p in params)
+        finite = all(bool(torch.isfinite(p.grad).all()) for p in params)
+        scale = scaler.get_scale()
+        scaler.step(opt)
+        scaler.update()
+        if finite:
+            break
+    assert finite, "gradients never became finite while the loss scale backed off"
+    amp = {n: p.grad.float() / scale for n, p in m.named_parameters() if p.requires_grad}
+    opt.zero_grad(set_to_none=True)
+    torch.nn.functional.cross_entropy(m(x)[0], torch.tensor([0, 2], device="cuda")).backward()      # fp32 head
+    for n, p in m.named_parameters():
+        if p.requires_grad and float(p.grad.norm()) > 1e-10 and not n.endswith("k_proj.bias"):
+            e = float((amp[n] - p.grad.float()).norm() / p.grad.float().norm())
+            assert e < 3e-2, (n, e)
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        ev = m(x)[0]
+    assert rel_to_max(ev.float().cpu().numpy(), g["logits"]) < 1e-3

@@ -178,7 +178,7 @@ KAPT_VERSIONS = ["v1", "v2", "v3"]
 KAPT_DESC_COUNTS = (2, 3, 1)
 
 
-def run_kapt_case(mod, cfg, class_file, B, name, descriptors=False):
+def run_kapt_case(mod, cfg, class_file, B, name, descriptors=False, init="cntn_split_uni_disc"):
     """Knowledge-aware prompts (training/kapt_head.py, text_prompt_init='cntn_split_uni_disc', the configuration of
     train_scripts/updrs_3cls_train_tulip.sh) on SYNTHETIC knowledge files (the real ./data/ke_* are not distributed):
     eval logits / text features / per-description logits, and train-mode gradients incl. the context MLPs."""
@@ -193,7 +193,7 @@ def run_kapt_case(mod, cfg, class_file, B, name, descriptors=False):
             synth.synth_knowledge_files(tmp, "updrs", n_cls, KAPT_VERSIONS)
         os.chdir(tmp)
         try:
-            model = build_reference(mod, cfg, class_file, text_prompt_init="cntn_split_uni_disc",
+            model = build_reference(mod, cfg, class_file, text_prompt_init=init,
                                     knowledge_version=list(KAPT_VERSIONS), cls_type="updrs", use_descriptor=descriptors)
         finally:
             os.chdir(cwd)
@@ -225,6 +225,77 @@ def run_kapt_case(mod, cfg, class_file, B, name, descriptors=False):
     print("wrote", path, n, "gradients", out["logits"].shape, out["desc_logits"].shape)
 
 
+def run_zeroshot_case(mod, cfg, class_file, B, name):
+    """The zero-shot branch (VitaCLIP_model.py:97-98,295-306): use_text_prompt_learning=False, class text features read
+    from a file, logits = exp(logit_scale) * normalise(video) @ normalise(text).T.  The text features are data of the
+    fixture (3 x E, synthetic, deliberately NOT unit length)."""
+    import tempfile
+    from gava_clip_amd.tokenizer import read_class_names
+    n_cls = len(read_class_names(class_file))
+    tf = torch.from_numpy(synth.normalish("input.zeroshot_text_features", (n_cls, cfg.embed_dim), 0).astype(np.float32)) * 1.7
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "tf.pth")
+        torch.save({"text_features": tf}, path)
+        model = build_reference(mod, cfg, class_file, use_text_prompt_learning=False, zeroshot_evaluation=True,
+                                zeroshot_text_features_path=path)
+    sd = synth.synth_state_dict(cfg, n_cls, 0)
+    keys = list(model.state_dict().keys())
+    assert set(keys) <= set(sd.keys()) and not any(k.startswith(("textual.", "prompt_learner.")) for k in keys)
+    model.load_state_dict({k: torch.from_numpy(sd[k]) for k in keys}, strict=True)
+    model.eval()
+    x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size, seed=1234))
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        logits, lmt, lvm = model(x)
+        cls_x, summary = model.visual(x)           # the L1 interface callers use directly (evaluation/iwa.py:212,230)
+    assert lmt is None and lvm is None
+    out = dict(logits=logits.numpy(), text_features_in=tf.numpy(), state_keys=np.array(keys),
+               visual_cls_x=cls_x.numpy(), visual_summary=summary.numpy())
+    path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, out["logits"].shape)
+
+
+def run_sigmoid_case(mod, cfg, class_file, B, name):
+    """use_sigmoid_loss=True (VitaCLIP_model.py:193-197,308-309): logit_scale starts at log(log 10), a learnable
+    logit_bias is added to the logits.  Both are set to non-default values here so that the test pins them."""
+    from gava_clip_amd.tokenizer import read_class_names
+    n_cls = len(read_class_names(class_file))
+    model = build_reference(mod, cfg, class_file, use_sigmoid_loss=True)
+    sd = synth.synth_state_dict(cfg, n_cls, 0)
+    sd["logit_scale"] = np.array(0.9, dtype=np.float32)
+    sd["logit_bias"] = np.array(-3.5, dtype=np.float32)
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    pl = model.prompt_learner
+    with torch.no_grad():
+        for idc in range(pl.n_cls):
+            emb = model.textual.token_embedding(pl.tokenized_prompts[idc])
+            pl.token_prefix[idc] = emb[:, :1, :]
+            pl.token_suffix[idc] = emb[:, 1 + pl.n_ctx:, :]
+    x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size, seed=1234))
+    model.eval()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        logits = model(x)[0]
+        # the text tower called directly, as evaluation/zero_shot.py:75-76 and utils/prepare_embedding.py do
+        tok = torch.cat(model.tokenized_prompts)
+        direct = model.textual(model.textual.token_embedding(tok), tok)
+    model.train()
+    w1 = torch.randn(B, n_cls, generator=torch.Generator().manual_seed(2024))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lg = model(x)[0]
+    (lg * w1).sum().backward()
+    out = dict(logits=logits.numpy(), w_logits=w1.numpy(), logit_scale=sd["logit_scale"], logit_bias=sd["logit_bias"],
+               textual_direct=direct.numpy(), tokens=tok.numpy().astype(np.int32))
+    for pname in ("logit_scale", "logit_bias", "prompt_learner.ctx", "visual.global_prompts"):
+        out["grad." + pname] = dict(model.named_parameters())[pname].grad.numpy()
+    path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, out["logits"])
+
+
 def dump_tokens(txt_mod):
     from gava_clip_amd.tokenizer import read_class_names, prompt_texts
     for fn in ("updrs_3cls_classes.txt", "k400_classes.txt"):
@@ -240,6 +311,12 @@ def dump_tokens(txt_mod):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     mod, txt_mod = import_reference()
+    C3 = os.path.join(CLASSES, "updrs_3cls_classes.txt")
+    if "--round2" in sys.argv:      # only the fixtures added in round 2 (the others are unchanged)
+        run_kapt_case(mod, TINY, C3, 2, "tiny_kapt_nodisc", init="cntn_split_uni")
+        run_zeroshot_case(mod, TINY, C3, 2, "tiny_zeroshot")
+        run_sigmoid_case(mod, TINY, C3, 2, "tiny_sigmoid")
+        sys.exit(0)
     dump_tokens(txt_mod)
     run_case(mod, TINY, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "tiny", True)
     run_case(mod, VIT_B16_T8, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "c1_b16", False)
@@ -248,3 +325,6 @@ if __name__ == "__main__":
     run_grad_case(mod, VIT_B16_T8, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 1, "b16_grads", False, sampled=True)
     run_kapt_case(mod, TINY, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "tiny_kapt")
     run_kapt_case(mod, TINY, os.path.join(CLASSES, "updrs_3cls_classes.txt"), 2, "tiny_kapt_desc", descriptors=True)
+    run_kapt_case(mod, TINY, C3, 2, "tiny_kapt_nodisc", init="cntn_split_uni")
+    run_zeroshot_case(mod, TINY, C3, 2, "tiny_zeroshot")
+    run_sigmoid_case(mod, TINY, C3, 2, "tiny_sigmoid")
