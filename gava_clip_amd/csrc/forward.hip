@@ -89,8 +89,10 @@ struct Carver {
   } while (0)
 
 int ln(const float* in, long in_stride, const int32_t* idx, const float* g, const float* b, void* o16, long o16s,
-       float* o32, long o32s, int rows, int D, int prec, gava_stream_t s, int split = 0) {
+       float* o32, long o32s, int rows, int D, int prec, gava_stream_t s, int split = 0, const float* g2 = nullptr,
+       const float* b2 = nullptr) {
   gava_layernorm_args a{};
+  a.gamma2 = g2; a.beta2 = b2;
   a.in = in; a.in_stride = in_stride; a.in_row_index = idx; a.gamma = g; a.beta = b;
   a.out16 = o16; a.out16_stride = o16s; a.out32 = o32; a.out32_stride = o32s;
   a.rows = rows; a.D = D; a.prec = prec; a.split_out = split;
@@ -99,8 +101,9 @@ int ln(const float* in, long in_stride, const int32_t* idx, const float* g, cons
 
 // LayerNorm folding (gava_gemm_args): producer outputs and/or consumer inputs of one GEMM call
 struct Fold {
-  void* x16 = nullptr; long ld_x16 = 0; float* rowsum = nullptr;                          // producer
+  void* x16 = nullptr; long ld_x16 = 0; float* rowsum = nullptr; int reduced = 0;         // producer
   const float* stats = nullptr; const float* s = nullptr; const float* t = nullptr;       // consumer
+  const float* partials = nullptr;                                                        // consumer, no row_stats launch
 };
 
 int gemm(const void* A, long lda, const void* W, long ldw, const float* bias, void* out, long ldo, int M, int N, int K,
@@ -109,8 +112,8 @@ int gemm(const void* A, long lda, const void* W, long ldw, const float* bias, vo
   gava_gemm_args a{};
   a.cu_reserve = cu_reserve;
   if (fold) {
-    a.x16_out = fold->x16; a.ld_x16 = fold->ld_x16; a.rowsum_out = fold->rowsum;
-    a.fold_stats = fold->stats; a.fold_s = fold->s; a.fold_t = fold->t;
+    a.x16_out = fold->x16; a.ld_x16 = fold->ld_x16; a.rowsum_out = fold->rowsum; a.rowsum_reduced = fold->reduced;
+    a.fold_stats = fold->stats; a.fold_s = fold->s; a.fold_t = fold->t; a.fold_partials = fold->partials;
   }
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo;
   a.resid = resid; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.prec = prec;
@@ -153,7 +156,10 @@ VisionWs carve_vision(const gava_vision_model* m, void* ws, size_t cap) {
   w.QC = c.take(BT * D * 2);
   w.MIXC = c.take(BT * 3 * D * 2);
   w.HIDC = c.take(BT * 3 * F * 2);
-  w.RSUM = (float*)c.take(R * (D / 64) * 8);
+  {
+    const long per_slot = R * (D / 64) * 8, reduced = (R + 255) / 256 * 256 * 4 * 8 + 1024;   // [R][D/64] or [R up to 256][4] float2
+    w.RSUM = (float*)c.take(per_slot > reduced ? per_slot : reduced);
+  }
   w.STATS = (float*)c.take((R + 255) / 256 * 256 * 8);
   w.total = (c.off + 255) & ~(size_t)255;
   return w;
@@ -234,7 +240,14 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
                ? GAVA_OK : GAVA_ELAUNCH;
   };
   TRY(keep(0));
-  TRY(ln(w.X, D, nullptr, m->lnpre_g, m->lnpre_b, nullptr, 0, w.X, D, R, D, pr, stream));
+  // ln_pre, and in the same row pass norm1 of block 0 (both read the same rows: one read of the embedding instead of two)
+  static const bool no_prefuse = getenv("GAVA_NO_PREFUSE") != nullptr;     // A/B switches (tools/ab_env.py)
+  static const bool no_lastfold = getenv("GAVA_NO_LASTFOLD") != nullptr;
+  // timing diagnostics only (results are WRONG): how much of a kernel's duration the forward gives back when it is removed
+  static const bool skip_attn = getenv("GAVA_DIAG_SKIP_ATTN") != nullptr, skip_stats = getenv("GAVA_DIAG_SKIP_STATS") != nullptr;
+  const bool pre_fused = m->layers >= 1 && !no_prefuse;
+  if (pre_fused) TRY(ln(w.X, D, nullptr, m->lnpre_g, m->lnpre_b, w.Xn, D, w.X, D, R, D, pr, stream, 0, m->layer[0].ln1_g, m->layer[0].ln1_b));
+  else TRY(ln(w.X, D, nullptr, m->lnpre_g, m->lnpre_b, nullptr, 0, w.X, D, R, D, pr, stream));
 
   // ---- blocks (VitaCLIP_vision_encoder.py:115-121, VitaCLIP_vision_encoder_utils.py:155-203)
   bool folded_in = false;   // Xn / STATS already hold this block's un-normalised input and its row statistics
@@ -275,13 +288,24 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
     const bool not_last = i + 1 < m->layers;
     const bool fold2 = !saved_x && not_last && L.w_fc1_fold && D % 64 == 0;
     const bool fold1 = folded_in;                                                    // set by the previous block's fc2
-    const bool fold1_next = !saved_x && i + 2 < m->layers && m->layer[i + 1].w_qkv_fold && D % 64 == 0;
-    Fold produce; produce.x16 = w.Xn; produce.ld_x16 = D; produce.rowsum = w.RSUM;
-    if (!fold1) TRY(ln(w.X, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
+    // (the last block consumes the fold too: its K/V GEMM over all rows; its CLS queries get a LayerNorm of their own)
+    const bool fold1_next = !saved_x && i + (no_lastfold ? 2 : 1) < m->layers && m->layer[i + 1].w_qkv_fold && D % 64 == 0;
+    // big batches: the producers pre-reduce their row sums per 256-column tile and the consumers turn them into
+    // (mean, rstd) themselves - no gava_row_stats launch between producer and consumer (each cost ~33 us of forward time
+    // for a 9 us kernel: two kernel boundaries behind a persistent GEMM).  GAVA_FUSED_STATS=0: the launch stays (A/B).
+    static const bool fused_env = !(getenv("GAVA_FUSED_STATS") && getenv("GAVA_FUSED_STATS")[0] == '0');
+    const bool fused = fused_env && R >= 8192 && D % 256 == 0 && D <= 1024 && D >= 256;
+    Fold produce; produce.x16 = w.Xn; produce.ld_x16 = D; produce.rowsum = w.RSUM; produce.reduced = fused ? 1 : 0;
+    auto consume = [&](const float* s_, const float* t_) {
+      Fold c; c.s = s_; c.t = t_;
+      if (fused) c.partials = w.RSUM; else c.stats = w.STATS;
+      return c;
+    };
+    if (!fold1 && !(i == 0 && pre_fused)) TRY(ln(w.X, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
     const unsigned short* sk = (const unsigned short*)w.SIDEKV;
     if (not_last) {
       if (fold1) {
-        Fold c; c.stats = w.STATS; c.s = L.qkv_fold_s; c.t = L.qkv_fold_t;
+        Fold c = consume(L.qkv_fold_s, L.qkv_fold_t);
         TRY(gemm(w.Xn, D, L.w_qkv_fold, D, nullptr, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, &c, resv));
       } else
       TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, nullptr, resv));
@@ -294,12 +318,12 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
         a.out = w.MIX; a.ld_out = D;
         a.batch = BT; a.heads = m->H; a.n_q = n + 1; a.n_kmain = n + 1;
         a.n_g = G; a.T = Tm; a.has_summary = 1; a.prec = pr;
-        TRY(gava_attention(&a, stream));
+        if (!skip_attn) TRY(gava_attention(&a, stream));
       }
       if (fold2) {
         TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
-        TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
-        Fold c; c.stats = w.STATS; c.s = L.fc1_fold_s; c.t = L.fc1_fold_t;
+        if (!skip_stats && !fused) TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
+        Fold c = consume(L.fc1_fold_s, L.fc1_fold_t);
         if (probe && hipEventRecord(g_probe.ev[i][0], s) != hipSuccess) return GAVA_ELAUNCH;
         TRY(gemm(w.Xn, D, L.w_fc1_fold, D, nullptr, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, &c));
         if (probe && hipEventRecord(g_probe.ev[i][1], s) != hipSuccess) return GAVA_ELAUNCH;
@@ -313,7 +337,7 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       if (probe) g_probe.n = i + 1;
       if (fold1_next) {
         TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
-        TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
+        if (!skip_stats && !fused) TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
       } else {
         TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D));
       }
@@ -323,13 +347,22 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       // takes x[:,0]; the summary token comes from the prompt path above).  Keys/values are still
       // needed for every token, queries / out_proj / MLP only for the B*T CLS rows: same results,
       // 1/197 of the row work.
-      TRY(gemm(w.Xn, D, wqkv + (long)D * D, D, L.b_qkv + D, (unsigned short*)w.QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, nullptr, resv));
+      if (fold1) {   // norm1 folded into the K/V GEMM: Xn holds the 16-bit copy of the un-normalised stream
+        Fold c = consume(L.qkv_fold_s + D, L.qkv_fold_t + D);
+        TRY(gemm(w.Xn, D, (const unsigned short*)L.w_qkv_fold + (long)D * D, D, nullptr, (unsigned short*)w.QKV + D, 3 * D, R, 2 * D, D,
+                 GAVA_EPI_H16, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, &c, resv));
+      } else {
+        TRY(gemm(w.Xn, D, wqkv + (long)D * D, D, L.b_qkv + D, (unsigned short*)w.QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, nullptr, resv));
+      }
       // split precision for these B*T rows when the model carries the split-packed weights (gava_vision_layer)
       const int sp = (!saved_x && L.w_q_split && L.w_out_split && L.w_fc1_split && L.w_fc2_split) ? 1 : 0;
       const int S = sp ? 3 : 1;
       if (sp) {
         TRY(ln(w.X, fs, nullptr, L.ln1_g, L.ln1_b, w.XNC, 3 * D, nullptr, 0, BT, D, pr, stream, 1));
         TRY(gemm(w.XNC, 3 * D, L.w_q_split, 3 * D, L.b_qkv, w.QC, D, BT, D, 3 * D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+      } else if (fold1) {
+        TRY(ln(w.X, fs, nullptr, L.ln1_g, L.ln1_b, w.XNC, D, nullptr, 0, BT, D, pr, stream));     // the B*T CLS rows only
+        TRY(gemm(w.XNC, D, L.w_qkv, D, L.b_qkv, w.QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
       } else {
         TRY(gemm(w.Xn, fs, L.w_qkv, D, L.b_qkv, w.QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
       }

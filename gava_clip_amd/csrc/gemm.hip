@@ -18,6 +18,7 @@
 #include "common.h"
 #include "internal.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <type_traits>
 
 // 1: set_src's lane-dependent terms are recomputed per tile instead of hoisted out of the tile loop (35 VGPRs less: the
@@ -34,6 +35,11 @@
 
 namespace {
 
+#ifdef GAVA_ENABLE_ABLATE
+#define ABLATE p.ablate
+#else
+#define ABLATE 0
+#endif
 constexpr int BK = 64;
 // s_waitcnt immediate for "vmcnt(n) only" on gfx9/CDNA: vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14
 
@@ -49,6 +55,9 @@ struct GemmParams {
   // LayerNorm folding: producer (EPI_F32) extras and consumer (EPI_H16*) inputs, see gava_hip.h
   unsigned short* x16; long ldx16; float2* rowsum;
   const float2* fstats; const float* fs; const float* ft;
+  int rowsum_reduced;          // producer (persistent kernel): rowsum is [rows][4] float2, one slot per 256-column tile
+  const float2* fpart;         // consumer (persistent FOLD kernel): those partials; it makes (mean, rstd) itself
+  int fold_slots; float fold_inv_d;
   int M, N, K;
   int scale_cols; float scale;
   const float* pos; const float* time; int n_patches; int T;
@@ -214,13 +223,13 @@ void gemm_kernel(const GemmParams p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (direct) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's A-tile ds_writes are done
     __builtin_amdgcn_s_barrier();
-    const bool refill = kt + NST - 1 < nk && !(p.ablate & 1);   // refills the slot every wave finished reading at kt-1
+    const bool refill = kt + NST - 1 < nk && !(ABLATE & 1);   // refills the slot every wave finished reading at kt-1
     if (refill) {
       stage(kt + NST - 1);
       if (direct) patch_load(kt + NST - 1);
     }
     const char* cur = smem + (kt % NST) * STAGE;
-    if (p.ablate & 2) continue;
+    if (ABLATE & 2) continue;
     s16x8_t af[2][4], wf[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -244,7 +253,7 @@ void gemm_kernel(const GemmParams p) {
     if (direct && refill) patch_write(kt + NST - 1);
   }
 
-  if (p.ablate & 4) return;
+  if (ABLATE & 4) return;
   // ---- epilogue: lane holds out[m][n .. n+3], m = m0+wr*64+i*16+fr, n = n0+wc*64+j*16+4*fg
   const int nbase = n0 + wc * 64 + 4 * fg;
   float4 bj[4];
@@ -396,7 +405,11 @@ void gemm256_kernel(const GemmParams p) {
   constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;   // 32 KiB, 64 KiB
   constexpr int PPW = (BM + BN) / 8 / NW;                            // 8 glds per wave per stage
   constexpr int NSTORE = (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH) ? 32 : (SPLIT ? 48 : 16);
-  constexpr bool ACC_RES = EPI == GAVA_EPI_F32 && RES;   // accumulators start at the residual tile
+  // accumulators start at the residual tile.  (Round 2 tried the other order - accumulators from zero, the residual
+  // row groups fetched by LDS-DMA during stages 1..8 and added one stage later, so that the epilogue is left with its
+  // stores: out_proj 0.277 vs 0.279 ms, fc2 0.591 vs 0.587 ms, plain out / fc2 4 % slower.  The epilogue's time is its
+  // stores, not the residual loads; removed.)
+  constexpr bool ACC_RES = EPI == GAVA_EPI_F32 && RES;
   // Column layout of the accumulators.  16-bit outputs: W rows are read in permuted order so that a lane ends with 16
   // consecutive columns (32 contiguous bytes, two b128 stores).  fp32 outputs (NAT): natural order, lane (fr, fg) holds
   // columns 16*jj + 4*fg + r, so that the four lanes of a row write / read 64 contiguous bytes per instruction - with the
@@ -417,7 +430,12 @@ void gemm256_kernel(const GemmParams p) {
   // touching 64
   constexpr bool X16_STAGE = EPI == GAVA_EPI_F32;
   constexpr int XS_PITCH = 128, XS_WAVE = 16 * XS_PITCH;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (CAN_FOLD ? 2 * FOLD_BYTES : 0) + (X16_STAGE ? NW * XS_WAVE : 0)];
+  // consumers in "partials" mode (p.fpart): (mean, rstd) pairs of the tile's 256 rows, shared by the workgroup, by tile parity
+  constexpr int PAIRS_OFF = 2 * STAGE + 2 * FOLD_BYTES, PAIRS_BYTES = 2 * 256 * 8;
+  // producers with p.rowsum_reduced: the four waves of a row half leave their (sum, sum^2) per row here [wr][row][wc]
+  constexpr int PS_OFF = 2 * STAGE + NW * XS_WAVE, PS_BYTES = 2 * 128 * 4 * 8;
+  constexpr int TAIL_LDS = (CAN_FOLD ? 2 * FOLD_BYTES + PAIRS_BYTES : 0) + (X16_STAGE ? NW * XS_WAVE + PS_BYTES : 0);
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + TAIL_LDS];
   constexpr bool fold = FOLD;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -434,7 +452,6 @@ void gemm256_kernel(const GemmParams p) {
   if (my_tiles == 0) return;
   const int nk = p.K / BK;
   const int G = my_tiles * nk;
-
   auto tile_coords = [&](int j, int& m0, int& n0) {
     const int wg = x_first + slot + j * per_xcd;
     const int per_group = p.sm * p.tiles_n;
@@ -484,7 +501,9 @@ void gemm256_kernel(const GemmParams p) {
       unsigned l16 = lane * 16u, l4 = lane * 4u;
       asm volatile("" : "+v"(l16), "+v"(l4));
       char* fb = smem + 2 * STAGE + (tj & 1) * FOLD_BYTES + wave * FOLD_WAVE;
-      const char* st = reinterpret_cast<const char*>(p.fstats) + (size_t)(mm0 + wr * 128) * 8;
+      // (mean, rstd) pairs of this wave's 128 rows, or - partials mode - the raw [4] float2 partials of ITS 32 of them
+      const char* st = p.fpart ? reinterpret_cast<const char*>(p.fpart) + (size_t)(mm0 + wr * 128 + wc * 32) * 32
+                               : reinterpret_cast<const char*>(p.fstats) + (size_t)(mm0 + wr * 128) * 8;
       const char* ss = reinterpret_cast<const char*>(p.fs) + (size_t)(nn0 + wc * 64) * 4;
       __builtin_amdgcn_global_load_lds(GLB_PTR(st + l16), LDS_PTR(void, fb), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(GLB_PTR(ss + l4), LDS_PTR(void, fb + 1024), 4, 0, 0);
@@ -511,12 +530,41 @@ void gemm256_kernel(const GemmParams p) {
 
   // accumulators of tile `tj` start at -mean_m * s_n: the MFMAs then leave x.W' - mean * s, the epilogue scales by rstd.
   // LDS reads by hand: the compiler would fence plain ones with vmcnt(0) against the LDS-DMA in flight.
+  // partials mode: (mean, rstd) of this wave's 32 rows from their (up to 4) partial sums, fixed order, into the shared
+  // pairs area of tile `tj`; a workgroup barrier has to lie between this and fold_init(tj) / the epilogue of tile tj
+  auto fold_reduce = [&](int tj) {
+    if (CAN_FOLD) {
+      const unsigned lb = (unsigned)(size_t)LDS_PTR(char, smem);
+      unsigned a = (lane & 31) * 32u;
+      asm volatile("" : "+v"(a));
+      unsigned pa = a >> 2;                                                       // 8 bytes per row
+      a += lb + 2 * STAGE + (tj & 1) * FOLD_BYTES + wave * FOLD_WAVE;
+      pa += lb + PAIRS_OFF + (tj & 1) * (PAIRS_BYTES / 2) + (wr * 128 + wc * 32) * 8;
+      f32x4_t q0, q1;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(q0) : "v"(a));
+      asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(q1) : "v"(a));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(q0), "+v"(q1));
+      float s1 = (q0[0] + q0[2]) + q1[0], s2 = (q0[1] + q0[3]) + q1[1];
+      if (p.fold_slots > 3) { s1 += q1[2]; s2 += q1[3]; }
+      const float mean = s1 * p.fold_inv_d;
+      const float var = fmaxf(s2 * p.fold_inv_d - mean * mean, 0.f);
+      const f32x2_t pr = {mean, 1.0f / sqrtf(var + 1e-5f)};
+      if (lane < 32) asm volatile("ds_write_b64 %0, %1" ::"v"(pa), "v"(pr) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
+  auto pairs_base = [&](int tj) -> unsigned {   // LDS address of the (mean, rstd) pair of this wave's row 0 of tile tj
+    const unsigned lb = (unsigned)(size_t)LDS_PTR(char, smem);
+    return p.fpart ? lb + PAIRS_OFF + (tj & 1) * (PAIRS_BYTES / 2) + wr * 1024
+                   : lb + 2 * STAGE + (tj & 1) * FOLD_BYTES + wave * FOLD_WAVE;
+  };
   auto fold_init = [&](int tj) {
     if (CAN_FOLD) {
       const unsigned fb = (unsigned)(size_t)LDS_PTR(char, smem) + 2 * STAGE + (tj & 1) * FOLD_BYTES + wave * FOLD_WAVE;
       unsigned a_s = (lane >> 4) * 64u, a_m = (lane & 15) * 8u;
       asm volatile("" : "+v"(a_s), "+v"(a_m));   // see fold_fetch
-      a_s += fb; a_m += fb;
+      a_s += fb; a_m += pairs_base(tj);
       f32x4_t sj[4];
       float mu[8];
 #pragma unroll
@@ -537,7 +585,18 @@ void gemm256_kernel(const GemmParams p) {
     }
   };
 
-  int m0, n0, m0n, n0n;
+  // producers with p.rowsum_reduced: (sum, sum^2) of a row over this tile's 256 columns = the four waves' partials in a
+  // fixed order, one float2 per row and 256-column tile: rowsum[row][4]
+  auto flush_rowsum = [&](int mm0, int nn0) {
+    if (X16_STAGE && tid < 256) {
+      const float4* q = reinterpret_cast<const float4*>(smem + PS_OFF + tid * 32);
+      const float4 a = q[0], b = q[1];
+      const int m = mm0 + tid;
+      if (m < p.M) p.rowsum[(long)m * 4 + nn0 / 256] = make_float2((a.x + a.z) + (b.x + b.z), (a.y + a.w) + (b.y + b.w));
+    }
+  };
+
+  int m0, n0, m0n, n0n, m0p = 0, n0p = 0;
   tile_coords(0, m0, n0);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -553,12 +612,20 @@ void gemm256_kernel(const GemmParams p) {
   if (CAN_FOLD) {
     fold_fetch(0, m0, n0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.fpart) {
+      fold_reduce(0);
+      __builtin_amdgcn_s_barrier();
+    }
     fold_init(0);
   }
   int counted = 0;   // the next wait may leave this wave's NSTORE (1) or 2*NSTORE (2: pre-activation copy) epilogue stores in flight
   // diagnostic stamps (gava_debug_set_buffer; tools/gemm_stamps.py): cycles in the vmcnt wait, the barrier,
   // the stage body and the epilogue
+#ifdef GAVA_STAMPS      // diagnostic builds only (tools/ab_build.sh stamps -DGAVA_STAMPS): the stamps cost scalar registers
   const bool stamp = p.dbg != nullptr;
+#else
+  constexpr bool stamp = false;
+#endif
   unsigned long long ts = 0, tW = 0, tB = 0, tC = 0, tE = 0;
   bool in_epi = false;
   if (stamp) ts = clock64();
@@ -577,6 +644,8 @@ void gemm256_kernel(const GemmParams p) {
       if (stamp) { const unsigned long long t = clock64(); tW += t - ts; ts = t; }
       __builtin_amdgcn_s_barrier();
       if (stamp) { const unsigned long long t = clock64(); tB += t - ts; ts = t; }
+      // every wave has left the previous tile's epilogue: its row-sum partials are complete in LDS
+      if (X16_STAGE && p.rowsum_reduced && kt == 0 && j > 0) flush_rowsum(m0p, n0p);
       // LDS-DMA issue is expensive (~100+ cycles per 1 KiB piece beside running MFMAs): the two waves
       // that share a SIMD (w and w+4) issue their 8 pieces half an iteration apart, so one of them
       // always feeds the matrix pipe.  Waves 0-3 issue here, waves 4-7 after the second MFMA group.
@@ -584,11 +653,17 @@ void gemm256_kernel(const GemmParams p) {
         if (g + 1 < G) {
           if (kt + 1 < nk) {
             stage(g + 1, kt + 1);
+            // partials mode: the next tile's partials are fetched three stages before the end of this tile, reduced one
+            // stage later (below) and published by the barrier of the last stage - before this tile's epilogue starts
+            if (CAN_FOLD && p.fpart && kt == nk - 3 && j + 1 < my_tiles) {
+              tile_coords(j + 1, m0n, n0n);
+              fold_fetch(j + 1, m0n, n0n);
+            }
           } else {
             tile_coords(j + 1, m0n, n0n);
             set_src(m0n, n0n);
             stage(g + 1, 0);
-            fold_fetch(j + 1, m0n, n0n);
+            if (!(CAN_FOLD && p.fpart)) fold_fetch(j + 1, m0n, n0n);
           }
         }
       };
@@ -630,6 +705,7 @@ void gemm256_kernel(const GemmParams p) {
         for (int jj = 0; jj < 4; ++jj) acc[4 + i][jj] = P::mfma(wf1[jj], a11[i], acc[4 + i][jj]);
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);   // a11
       __builtin_amdgcn_sched_group_barrier(0x008, 32, 1);  // a10 x wf1, a11 x wf1
+      if (CAN_FOLD && p.fpart && kt == nk - 2 && j + 1 < my_tiles) fold_reduce(j + 1);   // its fetch was waited for at this stage's start
     }
 
     if (stamp) { const unsigned long long t = clock64(); tC += t - ts; ts = t; in_epi = true; }
@@ -651,14 +727,14 @@ void gemm256_kernel(const GemmParams p) {
     unsigned a_r = (lane & 15) * 8u + 4u;
     if (CAN_FOLD) {
       asm volatile("" : "+v"(a_r));
-      a_r += (unsigned)(size_t)LDS_PTR(char, smem) + 2 * STAGE + (j & 1) * FOLD_BYTES + wave * FOLD_WAVE;
+      a_r += pairs_base(j);
       asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r_cur) : "v"(a_r) : "memory");
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int m = m0 + wr * 128 + i * 16 + fr;
       if (CAN_FOLD && i < 7) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r_next) : "v"(a_r), "n"((i + 1) * 128));
-      if (m < p.M && !(p.ablate & 4)) {
+      if (m < p.M && !(ABLATE & 4)) {
         long orow = m;
         const float* posr = nullptr;
         const float* timr = nullptr;
@@ -756,11 +832,13 @@ void gemm256_kernel(const GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) { ps1 += v[e]; ps2 += v[e] * v[e]; }
             ps1 = sum_across_lane_groups(ps1); ps2 = sum_across_lane_groups(ps2);
-            if (fg == 0) p.rowsum[orow * (p.N / 64) + (n0 + wc * 64) / 64] = make_float2(ps1, ps2);
+            if (p.rowsum_reduced) {
+              if (fg == 0) *reinterpret_cast<float2*>(smem + PS_OFF + ((wr * 128 + i * 16 + fr) * 4 + wc) * 8) = make_float2(ps1, ps2);
+            } else if (fg == 0) p.rowsum[orow * (p.N / 64) + (n0 + wc * 64) / 64] = make_float2(ps1, ps2);
           }
         }
       }
-      if (X16_STAGE && p.x16 && !(p.ablate & 4)) {
+      if (X16_STAGE && p.x16 && !(ABLATE & 4)) {
         // lane l: row (l >> 3) (+8 in the second pass), 16-byte chunk (l & 7) of the 128-byte row segment
         const char* xs = smem + 2 * STAGE + wave * XS_WAVE;
 #pragma unroll
@@ -786,310 +864,29 @@ void gemm256_kernel(const GemmParams p) {
     }
     if (CAN_FOLD && j + 1 < my_tiles) {
       // the next tile's fold block was issued before this epilogue's stores: it has landed once at most those are in flight
-      if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE <= 63 ? NSTORE : 0) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (partials mode: it landed, and was reduced, two stages ago)
+      if (!p.fpart) {
+        if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE <= 63 ? NSTORE : 0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       fold_init(j + 1);
     }
     // a full tile issued exactly NSTORE stores per wave after the in-flight stage: they may stay in flight
     // over the next wait (ragged tiles store fewer, and the accumulator-residual loads add to the count:
     // those cases fall back to vmcnt(0)).
-    counted = (full && !ACC_RES && !(p.ablate & 4) && !(EPI == GAVA_EPI_F32 && p.x16)) ? ((EPI == GAVA_EPI_H16_QGELU && p.aux_out) ? 2 : 1) : 0;
+    counted = (full && !ACC_RES && !(ABLATE & 4) && !(EPI == GAVA_EPI_F32 && p.x16)) ? ((EPI == GAVA_EPI_H16_QGELU && p.aux_out) ? 2 : 1) : 0;
+    m0p = m0; n0p = n0;
     m0 = m0n; n0 = n0n;
+  }
+  if (X16_STAGE && p.rowsum_reduced) {
+    __syncthreads();
+    flush_rowsum(m0p, n0p);
   }
   if (stamp && lane == 0) {
     const unsigned long long t = clock64();
     tE += t - ts;
     unsigned long long* d = p.dbg + (size_t)(blockIdx.x * 8 + wave) * 8;
     d[0] = tW; d[1] = tB; d[2] = tC; d[3] = 0; d[4] = tE; d[5] = (unsigned long long)G;
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// v7 "rotated-k": v3 whose two wave groups (waves 0-3 / 4-7, the SIMD partners) are E operand stages out
-// of phase, so that each group's epilogue - VALU, conversions and the store issue tail - runs while its
-// partner feeds the matrix pipe.
-//   * The operand stream of a tile has CYC = nk + E stages: k-slices 0..nk-1, then slices 0..E-1 again.
-//     Every wave is at the same stream position (one barrier per stage, as in v3), every wave issues its
-//     share of each stage's LDS-DMA.
-//   * Both groups run ONE program - [epilogue of the previous tile in E chunks] [nk compute stages] - and
-//     group 1 simply skips the first (empty) epilogue phase.  Group 1 therefore computes a tile on stream
-//     stages 0..nk-1 and stores it on nk..CYC-1; group 0 stores the previous tile on stages 0..E-1 and
-//     computes on E..CYC-1, i.e. slices E..nk-1, 0..E-1: the same sum in a rotated order.
-//   * An MFMA never cares which k-slice it gets, only which LDS slot: slot = stream position & 1.
-// Cost: E/nk more L2->LDS traffic.  Gain: the epilogue leaves the critical path of the matrix pipe.
-template <class P, int EPI, bool RES, bool SPLIT, int E>
-__global__ __launch_bounds__(512, 2)
-void gemm256r_kernel(const GemmParams p) {
-  constexpr int BM = 256, BN = 256, NW = 8;
-  constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;   // 32 KiB, 64 KiB
-  constexpr int PPW = (BM + BN) / 8 / NW;                            // 8 glds per wave per stage
-  constexpr int RPC = 8 / E;                                         // accumulator rows per epilogue chunk
-  constexpr int ROW_STORES = (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH) ? 4 : (SPLIT ? 6 : 2);
-  constexpr int CH_STORES = RPC * ROW_STORES;
-  constexpr bool ACC_RES = EPI == GAVA_EPI_F32 && RES;   // accumulators start at the residual tile
-  static_assert(E == 2 || E == 4 || E == 8, "chunks must tile the 8 accumulator rows");
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int fr = lane & 15, fg = lane >> 4;
-
-  const int nwg = p.n_tiles, nb = gridDim.x;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = nb >> 3;
-  const int q = nwg >> 3, r = nwg & 7;
-  const int x_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int x_count = xcd < r ? q + 1 : q;
-  const int my_tiles = slot < x_count ? (x_count - slot + per_xcd - 1) / per_xcd : 0;
-  if (my_tiles == 0) return;
-  const int nk = p.K / BK;
-  const int CYC = nk + E;
-  const int S = my_tiles * CYC;   // stream length in stages
-
-  auto tile_coords = [&](int j, int& m0, int& n0) {
-    const int wg = x_first + slot + j * per_xcd;
-    const int per_group = p.sm * p.tiles_n;
-    const int g = wg / per_group, first_m = g * p.sm;
-    const int sm = min(p.sm, p.tiles_m - first_m);
-    const int w = wg - g * per_group;
-    const int chunk = w / (sm * p.sn), rr = w - chunk * (sm * p.sn);
-    m0 = (first_m + rr % sm) * BM;
-    n0 = (chunk * p.sn + rr / sm) * BN;
-  };
-
-  unsigned src[PPW];
-  auto set_src = [&](int m0, int n0) {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int piece = wave + i * NW;
-      const int row = (piece & 31) * 8 + (lane >> 3);
-      if (i < PPW / 2) {
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        int gm = m0 + row;
-        gm = gm < p.M ? gm : p.M - 1;
-        src[i] = (unsigned)gm * (unsigned)p.lda + chunk * 8;
-      } else {
-        const int chunk = (lane & 7) ^ (((row >> 1) & 1) | (((row >> 4) & 3) << 1));
-        src[i] = (unsigned)(n0 + row) * (unsigned)p.ldw + chunk * 8;
-      }
-    }
-  };
-  auto stage = [&](int sl, int kt) {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR((i < PPW / 2 ? p.A : p.W) + (size_t)(src[i] + (unsigned)(kt * BK))),
-                                       LDS_PTR(void, smem + sl * STAGE + (wave + i * NW) * 1024), 16, 0, 0);
-  };
-
-  // the stream cursor: next stage to be fetched (tile dj, in-cycle index dr, position dpos)
-  int dj = 0, dr = 0, dpos = 0, dm0, dn0;
-  auto dma_next = [&]() {
-    if (dj < my_tiles) {
-      stage(dpos & 1, dr < nk ? dr : dr - nk);
-      ++dpos;
-      if (++dr == CYC) {
-        dr = 0;
-        if (++dj < my_tiles) {
-          tile_coords(dj, dm0, dn0);
-          set_src(dm0, dn0);
-        }
-      }
-    }
-  };
-
-  const int swa = fr >> 1;
-  const int swb = ((fr >> 1) & 1) | ((fr >> 2) << 1);
-  const int a_off = (wr * 128 + fr) * 128;
-  const int w_off = A_BYTES + (wc * 64 + 16 * (fr >> 2) + (fr & 3)) * 128;
-  const int a_k0 = (fg ^ swa) << 4, a_k1 = ((4 + fg) ^ swa) << 4;
-  const int w_k0 = (fg ^ swb) << 4, w_k1 = ((4 + fg) ^ swb) << 4;
-
-  f32x4_t acc[8][4];
-  auto load_resid = [&](int i, int mm0, int nn0) {
-    int m = mm0 + wr * 128 + i * 16 + fr;
-    m = m < p.M ? m : p.M - 1;
-    const float* rp = p.resid + (long)m * p.ldr + nn0 + wc * 64 + 16 * fg;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = *reinterpret_cast<const f32x4_t*>(rp + 4 * jj);
-  };
-
-  int m0p = 0, n0p = 0, m0c, n0c;
-  tile_coords(0, m0c, n0c);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (ACC_RES) {
-      load_resid(i, m0c, n0c);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  tile_coords(0, dm0, dn0);
-  set_src(dm0, dn0);
-  dma_next();   // stream position 0
-
-  int pos = 0;
-  bool counted = false;   // the next wait may leave this wave's CH_STORES chunk stores in flight
-  auto sync = [&]() {
-    if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH_STORES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    counted = false;
-    __builtin_amdgcn_s_barrier();
-  };
-
-  bool skip = wr == 1;   // group 1 starts in its compute phase
-  for (int c = 0; c <= my_tiles; ++c) {
-    if (c > 0 && c < my_tiles) tile_coords(c, m0c, n0c);
-    if (!skip) {
-      // ---- epilogue of tile c-1 in E chunks, one stream stage each; lane holds out[m][n .. n+15],
-      //      m = m0p + wr*128 + i*16 + fr, n = n0p + wc*64 + 16*fg + 4*jj + r
-      const int nb0 = n0p + wc * 64 + 16 * fg;
-      float4 bj[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-        bj[jj] = (p.bias && c > 0) ? *reinterpret_cast<const float4*>(p.bias + nb0 + 4 * jj) : make_float4(0, 0, 0, 0);
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) asm volatile("" ::"v"(bj[jj].x), "v"(bj[jj].y), "v"(bj[jj].z), "v"(bj[jj].w));   // wait once, here
-      const bool full = m0p + BM <= p.M;
-      auto chunk = [&](auto CH) __attribute__((always_inline)) {
-        constexpr int ch = decltype(CH)::value;
-        if (pos < S) {
-          sync();
-          dma_next();
-        }
-        ++pos;
-        if (c == 0) return;
-#pragma unroll
-        for (int ii = 0; ii < RPC; ++ii) {
-          const int i = ch * RPC + ii;
-          const int m = m0p + wr * 128 + i * 16 + fr;
-          if (m < p.M && !(p.ablate & 4)) {
-            long orow = m;
-            const float* posr = nullptr;
-            const float* timr = nullptr;
-            if (EPI == GAVA_EPI_F32_PATCH) {
-              const int frame = m / p.n_patches, pp = m - frame * p.n_patches;
-              orow = (long)frame * (p.n_patches + 1) + 1 + pp;
-              posr = p.pos + (long)(1 + pp) * p.N + nb0;
-              timr = p.time + (long)(frame % p.T) * p.N + nb0;
-            }
-            float v[16];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              v[4 * jj + 0] = acc[i][jj][0] + bj[jj].x; v[4 * jj + 1] = acc[i][jj][1] + bj[jj].y;
-              v[4 * jj + 2] = acc[i][jj][2] + bj[jj].z; v[4 * jj + 3] = acc[i][jj][3] + bj[jj].w;
-            }
-            if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU) {
-              if (EPI == GAVA_EPI_H16) {
-                if (nb0 < p.scale_cols) {
-#pragma unroll
-                  for (int e = 0; e < 16; ++e) v[e] *= p.scale;
-                }
-              } else {
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) quick_gelu2(v[e], v[e + 1]);
-              }
-              unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + nb0;
-              if (SPLIT) {
-                uint2 hi[4], lo[4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) split4<P>(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3], hi[jj], lo[jj]);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                  const uint4 H = make_uint4(hi[2 * h].x, hi[2 * h].y, hi[2 * h + 1].x, hi[2 * h + 1].y);
-                  const uint4 L = make_uint4(lo[2 * h].x, lo[2 * h].y, lo[2 * h + 1].x, lo[2 * h + 1].y);
-                  *reinterpret_cast<uint4*>(o + 8 * h) = H;
-                  *reinterpret_cast<uint4*>(o + p.N + 8 * h) = L;
-                  *reinterpret_cast<uint4*>(o + 2 * p.N + 8 * h) = H;
-                }
-              } else {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                  const uint2 x = pack4<P>(v[8 * h], v[8 * h + 1], v[8 * h + 2], v[8 * h + 3]);
-                  const uint2 y = pack4<P>(v[8 * h + 4], v[8 * h + 5], v[8 * h + 6], v[8 * h + 7]);
-                  *reinterpret_cast<uint4*>(o + 8 * h) = make_uint4(x.x, x.y, y.x, y.y);
-                }
-              }
-            } else {
-              float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + nb0;
-              if (EPI == GAVA_EPI_F32_PATCH) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                  const float4 pr = *reinterpret_cast<const float4*>(posr + 4 * jj);
-                  const float4 tr = *reinterpret_cast<const float4*>(timr + 4 * jj);
-                  v[4 * jj] += pr.x + tr.x; v[4 * jj + 1] += pr.y + tr.y; v[4 * jj + 2] += pr.z + tr.z; v[4 * jj + 3] += pr.w + tr.w;
-                }
-              }
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj)
-                *reinterpret_cast<float4*>(o + 4 * jj) = make_float4(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
-            }
-          }
-          // this group's next tile: its residual rows go straight into the accumulators just freed
-          if (ACC_RES && c < my_tiles) {
-            load_resid(i, m0c, n0c);
-          } else {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          }
-        }
-        // a full tile issued exactly CH_STORES stores after this stage's LDS-DMA: they may stay in flight
-        counted = full && !ACC_RES && !(p.ablate & 4);
-      };
-      chunk(std::integral_constant<int, 0>{});
-      chunk(std::integral_constant<int, 1>{});
-      if constexpr (E > 2) { chunk(std::integral_constant<int, 2>{}); chunk(std::integral_constant<int, 3>{}); }
-      if constexpr (E > 4) {
-        chunk(std::integral_constant<int, 4>{}); chunk(std::integral_constant<int, 5>{});
-        chunk(std::integral_constant<int, 6>{}); chunk(std::integral_constant<int, 7>{});
-      }
-    }
-    skip = false;
-    if (c == my_tiles) break;
-
-    for (int kt = 0; kt < nk; ++kt) {
-      sync();
-      if (wave < 4) dma_next();
-      const char* cur = smem + (pos & 1) * STAGE;
-      ++pos;
-      s16x8_t wf0[4], wf1[4], a00[4], a01[4], a10[4], a11[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) wf0[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 512 + w_k0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a00[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 2048 + a_k0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a01[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + (4 + i) * 2048 + a_k0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = P::mfma(wf0[jj], a00[i], acc[i][jj]);
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) wf1[jj] = *reinterpret_cast<const s16x8_t*>(cur + w_off + jj * 512 + w_k1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a10[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + i * 2048 + a_k1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[4 + i][jj] = P::mfma(wf0[jj], a01[i], acc[4 + i][jj]);
-      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-      if (wave >= 4) dma_next();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a11[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + (4 + i) * 2048 + a_k1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = P::mfma(wf1[jj], a10[i], acc[i][jj]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[4 + i][jj] = P::mfma(wf1[jj], a11[i], acc[4 + i][jj]);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
-      __builtin_amdgcn_sched_group_barrier(0x008, 32, 1);
-    }
-    m0p = m0c; n0p = n0c;
   }
 }
 
@@ -1115,22 +912,19 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
   const int reserve = forced >= 0 ? forced : (gp.cu_reserve > 0 ? gp.cu_reserve : 0);
   const int avail = n_cu - reserve > 8 ? (n_cu - reserve) / 8 * 8 : 8;
   const int blocks = gp.n_tiles < avail ? (gp.n_tiles + 7) / 8 * 8 : avail;
+  // (A W-stationary tile walk - an XCD stays on one chunk of weight panels and walks down the M-groups - was measured in
+  // round 2, tools/r2_walk.sh: fabric fetch unchanged (FETCH_SIZE 421 -> 432 MB per fc1 launch), 3-6 % slower; removed.)
   dim3 grid(blocks), block(512);
-#define GAVA_LAUNCH(EPI, RES, SPLIT)                                                               \
-  do {                                                                                             \
-    if (KERN == 7) hipLaunchKernelGGL((gemm256r_kernel<P, EPI, RES, SPLIT, 2>), grid, block, 0, s, gp); \
-    else if (KERN == 8) hipLaunchKernelGGL((gemm256r_kernel<P, EPI, RES, SPLIT, 4>), grid, block, 0, s, gp); \
-    else hipLaunchKernelGGL((gemm256_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp);         \
-  } while (0)
+#define GAVA_LAUNCH(EPI, RES, SPLIT) hipLaunchKernelGGL((gemm256_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp)
   switch (epi) {
     case GAVA_EPI_H16:
-      if (gp.fstats) {   // folded LayerNorm: its own instantiation, the plain kernels stay as they were
+      if (gp.fstats || gp.fpart) {   // folded LayerNorm: its own instantiation, the plain kernels stay as they were
         if (KERN != 3 || gp.split_out) return GAVA_EINVAL;
         hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_H16, false, false, true>), grid, block, 0, s, gp);
       } else if (gp.split_out) GAVA_LAUNCH(GAVA_EPI_H16, false, true); else GAVA_LAUNCH(GAVA_EPI_H16, false, false);
       break;
     case GAVA_EPI_H16_QGELU:
-      if (gp.fstats) {
+      if (gp.fstats || gp.fpart) {
         if (KERN != 3 || gp.split_out) return GAVA_EINVAL;
         hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_H16_QGELU, false, false, true>), grid, block, 0, s, gp);
       } else if (gp.split_out) GAVA_LAUNCH(GAVA_EPI_H16_QGELU, false, true); else GAVA_LAUNCH(GAVA_EPI_H16_QGELU, false, false);
@@ -1154,19 +948,22 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
 template <class P>
 int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   static const int variant = getenv("GAVA_GEMM_VARIANT") ? atoi(getenv("GAVA_GEMM_VARIANT")) : 0;
+  if (gp.rowsum_reduced || gp.fpart) {   // only the persistent kernel implements these; never fall back silently
+    const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
+    return (gp.N % 256 == 0 && fits && !gp.frames) ? launch_256<P, 3>(gp, epi, s) : GAVA_EINVAL;
+  }
   // small-M problems (prompt path, text tower at few classes): 128x128 tiles fill more CUs;
   // the im2col-free patch loader lives in the templated kernel
   // im2col-free patch embedding: 128 x 256 tiles (8 waves) build every A tile for 3 instead of 6 N-tiles at D = 768
   if (gp.frames && gp.N % 256 == 0 && variant != 1 && variant != 10) return launch_tile<P, 128, 256, 2>(gp, epi, s);
   if (gp.frames || gp.M <= 2048 || variant == 1 || variant == 10) return launch_tile<P, 128, 128, 2>(gp, epi, s);
   if (variant == 2) return launch_tile<P, 256, 128, 3>(gp, epi, s);
+  if (variant == 12 && gp.N % 256 == 0) return launch_tile<P, 128, 256, 2>(gp, epi, s);
+  if (variant == 13 && gp.N % 256 == 0) return launch_tile<P, 128, 256, 3>(gp, epi, s);
   // measured at M = 100864 (c2): the persistent 256^2 kernel wins for N >= 1536 (qkv 0.42 vs 0.58 ms,
   // fc1 0.55 vs 0.78 ms) and, since the static wave priority, for the deep-K N = 768 GEMM (fc2 0.59 vs
   // 0.62 ms); the shallow one (out, K = 768: 0.28 vs 0.26 ms) stays on the 128^2 kernel, whose many small
   // workgroups spread the fp32 residual traffic better over its short k-loop
-  const bool fits32r = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
-  if (gp.N % 256 == 0 && gp.K >= 256 && fits32r && variant == 7) return launch_256<P, 7>(gp, epi, s);
-  if (gp.N % 256 == 0 && gp.K >= 256 && fits32r && variant == 8) return launch_256<P, 8>(gp, epi, s);
   const bool fits32 = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
   const long tiles256 = (long)((gp.M + 255) / 256) * (gp.N / 256);
   // ... and, since the fp32-output kernels use the natural column order (64 contiguous bytes per row and instruction in
@@ -1200,6 +997,10 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   if (a->x16_out && (a->epilogue != GAVA_EPI_F32 || !a->rowsum_out || a->ld_x16 % 8 || ((uintptr_t)a->x16_out & 15) || ((uintptr_t)a->rowsum_out & 7))) return GAVA_EINVAL;
   if (a->fold_stats && ((a->epilogue != GAVA_EPI_H16 && a->epilogue != GAVA_EPI_H16_QGELU) || a->bias || !a->fold_s || !a->fold_t ||
                         (((uintptr_t)a->fold_stats | (uintptr_t)a->fold_s | (uintptr_t)a->fold_t) & 15))) return GAVA_EINVAL;
+  if (a->fold_partials && (a->fold_stats || (a->epilogue != GAVA_EPI_H16 && a->epilogue != GAVA_EPI_H16_QGELU) || a->bias || !a->fold_s ||
+                           !a->fold_t || a->split_out || a->K > 1024 || a->K < 4 * BK || a->N % 256 ||
+                           (((uintptr_t)a->fold_partials | (uintptr_t)a->fold_s | (uintptr_t)a->fold_t) & 15))) return GAVA_EINVAL;
+  if (a->rowsum_reduced && (!a->x16_out || a->N % 256 || a->N > 1024)) return GAVA_EINVAL;
   if (a->aux_out && (a->epilogue != GAVA_EPI_H16_QGELU || a->split_out || ((uintptr_t)a->aux_out & 15) || a->ldo % 8)) return GAVA_EINVAL;
   if (a->epilogue == GAVA_EPI_F32 && a->resid && (a->ldr % 4 || ((uintptr_t)a->resid & 15))) return GAVA_EINVAL;
   if (a->epilogue == GAVA_EPI_F32_PATCH &&
@@ -1212,7 +1013,9 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.aux = (const unsigned short*)a->aux; gp.aux_f16 = a->aux_prec == GAVA_PREC_F16; gp.aux_out = (unsigned short*)a->aux_out;
   gp.x16 = (unsigned short*)a->x16_out; gp.ldx16 = a->ld_x16; gp.rowsum = (float2*)a->rowsum_out;
   gp.fstats = (const float2*)a->fold_stats; gp.fs = a->fold_s; gp.ft = a->fold_t;
-  if (a->fold_stats) gp.bias = a->fold_t;   // t_n takes the bias registers of the epilogue
+  gp.rowsum_reduced = a->rowsum_reduced; gp.fpart = (const float2*)a->fold_partials;
+  gp.fold_slots = (a->K + 255) / 256; gp.fold_inv_d = 1.0f / (float)a->K;
+  if (a->fold_stats || a->fold_partials) gp.bias = a->fold_t;   // t_n takes the bias registers of the epilogue
   gp.M = a->M; gp.N = a->N; gp.K = a->K;
   gp.scale_cols = a->scale_cols; gp.scale = a->scale;
   gp.pos = a->pos; gp.time = a->time; gp.n_patches = a->n_patches; gp.T = a->T;

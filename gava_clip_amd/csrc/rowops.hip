@@ -42,6 +42,7 @@ struct LnParams {
   unsigned short* out16; long o16_stride;
   float* out32; long o32_stride;
   int rows, D, split;
+  const float* gamma2; const float* beta2;
 };
 
 template <class P>
@@ -71,6 +72,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
         v[i].z = v[i].z * g.z + b.z; v[i].w = v[i].w * g.w + b.w;
       }
   }
+  if (p.gamma2) {
+    // second LayerNorm on the first one's result: out32 gets the first, out16 the second
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (act[i] && p.out32) *reinterpret_cast<float4*>(p.out32 + (long)row * p.o32_stride + (lane + 64 * i) * 4) = v[i];
+    ln_row(v, 0, p.D, act);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (act[i]) {
+        const int c = (lane + 64 * i) * 4;
+        const float4 g = *reinterpret_cast<const float4*>(p.gamma2 + c);
+        const float4 b = *reinterpret_cast<const float4*>(p.beta2 + c);
+        v[i].x = v[i].x * g.x + b.x; v[i].y = v[i].y * g.y + b.y;
+        v[i].z = v[i].z * g.z + b.z; v[i].w = v[i].w * g.w + b.w;
+      }
+  }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
     if (act[i]) {
@@ -87,7 +104,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
           store_h16x4<P>(o, v[i]);
         }
       }
-      if (p.out32) *reinterpret_cast<float4*>(p.out32 + (long)row * p.o32_stride + c) = v[i];
+      if (p.out32 && !p.gamma2) *reinterpret_cast<float4*>(p.out32 + (long)row * p.o32_stride + c) = v[i];
     }
 }
 
@@ -262,22 +279,31 @@ __global__ void text_feature_kernel(const float* tn, float* tf, int C, int n_kv,
   }
 }
 
-// (mean, rstd) of each row from the GEMM epilogues' per-64-column partial sums, fixed summation order
-__global__ void row_stats_kernel(const float2* part, int slots, float inv_d, int rows, float2* stats) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
+// (mean, rstd) of each row from the GEMM epilogues' per-64-column partial sums, fixed summation order.  A block owns 64
+// consecutive rows = one contiguous run of 64 * slots float2: it is loaded coalesced into LDS (a thread per row would read
+// with a stride of slots * 8 bytes), then one thread per row sums its slots in order.
+constexpr int RS_ROWS = 64, RS_MAX_SLOTS = 32;
+__global__ __launch_bounds__(256) void row_stats_kernel(const float2* part, int slots, float inv_d, int rows, float2* stats) {
+  __shared__ float2 buf[RS_ROWS * RS_MAX_SLOTS];
+  const int r0 = blockIdx.x * RS_ROWS;
+  const int n = min(RS_ROWS, rows - r0) * slots;
+  const float2* src = part + (long)r0 * slots;
+  for (int i = threadIdx.x; i < n; i += 256) buf[i] = src[i];
+  __syncthreads();
+  const int r = threadIdx.x;
+  if (r >= RS_ROWS || r0 + r >= rows) return;
   float s1 = 0.f, s2 = 0.f;
-  for (int k = 0; k < slots; ++k) { const float2 v = part[(long)r * slots + k]; s1 += v.x; s2 += v.y; }
+  for (int k = 0; k < slots; ++k) { const float2 v = buf[r * slots + k]; s1 += v.x; s2 += v.y; }
   const float mean = s1 * inv_d;
   const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
-  stats[r] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+  stats[r0 + r] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
 }
 
 }  // namespace
 
 extern "C" int gava_row_stats(const float* rowsum, int slots, int D, int rows, float* stats, gava_stream_t stream) {
-  if (!rowsum || !stats || slots <= 0 || D <= 0 || rows <= 0) return GAVA_EINVAL;
-  hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  if (!rowsum || !stats || slots <= 0 || slots > RS_MAX_SLOTS || D <= 0 || rows <= 0) return GAVA_EINVAL;
+  hipLaunchKernelGGL(row_stats_kernel, dim3((rows + RS_ROWS - 1) / RS_ROWS), dim3(256), 0, (hipStream_t)stream,
                      (const float2*)rowsum, slots, 1.0f / (float)D, rows, (float2*)stats);
   GAVA_CHECK_LAUNCH();
   return GAVA_OK;
@@ -290,9 +316,10 @@ extern "C" int gava_layernorm(const gava_layernorm_args* a, gava_stream_t stream
   if (!a->out16 && !a->out32) return GAVA_EINVAL;
   if (a->split_out && (!a->out16 || a->out16_stride < 3 * (int64_t)a->D)) return GAVA_EINVAL;
   if (a->gamma && !a->beta) return GAVA_EINVAL;
+  if ((a->gamma2 != nullptr) != (a->beta2 != nullptr) || (a->gamma2 && (!a->gamma || !a->out16 || !a->out32))) return GAVA_EINVAL;
   if (a->in_stride % 4 || (a->out16 && a->out16_stride % 4) || (a->out32 && a->out32_stride % 4)) return GAVA_EINVAL;
   LnParams p{a->in, a->in_stride, a->in_row_index, a->gamma, a->beta, (unsigned short*)a->out16,
-             a->out16_stride, a->out32, a->out32_stride, a->rows, a->D, a->split_out};
+             a->out16_stride, a->out32, a->out32_stride, a->rows, a->D, a->split_out, a->gamma2, a->beta2};
   dim3 grid((a->rows + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (a->prec == GAVA_PREC_F16) hipLaunchKernelGGL(layernorm_kernel<PrecF16>, grid, block, 0, s, p);

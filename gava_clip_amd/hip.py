@@ -35,13 +35,15 @@ class GemmArgs(C.Structure):
                 ("frames", _fp), ("frame_size", C.c_int), ("patch", C.c_int), ("split_out", C.c_int),
                 ("aux", _vp), ("aux_prec", C.c_int), ("aux_out", _vp),
                 ("x16_out", _vp), ("ld_x16", C.c_int64), ("rowsum_out", _fp),
-                ("fold_stats", _fp), ("fold_s", _fp), ("fold_t", _fp), ("cu_reserve", C.c_int)]
+                ("fold_stats", _fp), ("fold_s", _fp), ("fold_t", _fp), ("cu_reserve", C.c_int),
+                ("rowsum_reduced", C.c_int), ("fold_partials", _fp)]
 
 
 class LayerNormArgs(C.Structure):
     _fields_ = [("inp", _fp), ("in_stride", C.c_int64), ("in_row_index", _ip), ("gamma", _fp), ("beta", _fp),
                 ("out16", _vp), ("out16_stride", C.c_int64), ("out32", _fp), ("out32_stride", C.c_int64),
-                ("rows", C.c_int), ("D", C.c_int), ("prec", C.c_int), ("split_out", C.c_int)]
+                ("rows", C.c_int), ("D", C.c_int), ("prec", C.c_int), ("split_out", C.c_int),
+                ("gamma2", _fp), ("beta2", _fp)]
 
 
 class AttentionArgs(C.Structure):
@@ -209,9 +211,10 @@ def h16_dtype(prec):
 def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0,
          pos=None, time=None, n_patches=0, T=0, M=None, split_out=False, frames=None, frame_size=0, patch=0, aux=None,
          aux_prec=None, aux_out=None, x16_out=None, rowsum_out=None, fold_stats=None, fold_s=None, fold_t=None,
-         cu_reserve=0):
+         cu_reserve=0, rowsum_reduced=False, fold_partials=None):
     a = GemmArgs()
     a.cu_reserve = cu_reserve
+    a.rowsum_reduced, a.fold_partials = int(rowsum_reduced), ptr(fold_partials)
     a.x16_out, a.ld_x16, a.rowsum_out = ptr(x16_out), (x16_out.stride(0) if x16_out is not None else 0), ptr(rowsum_out)
     a.fold_stats, a.fold_s, a.fold_t = ptr(fold_stats), ptr(fold_s), ptr(fold_t)
     a.aux, a.aux_out = ptr(aux), ptr(aux_out)
@@ -228,8 +231,9 @@ def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0
 
 
 def layernorm(x, gamma, beta, *, out16=None, out32=None, prec, rows=None, in_stride=None, row_index=None,
-              split_out=False):
+              split_out=False, gamma2=None, beta2=None):
     a = LayerNormArgs()
+    a.gamma2, a.beta2 = ptr(gamma2), ptr(beta2)
     a.inp, a.in_stride, a.in_row_index = ptr(x), (x.stride(0) if in_stride is None else in_stride), ptr(row_index)
     a.gamma, a.beta = ptr(gamma), ptr(beta)
     a.out16, a.out16_stride = ptr(out16), (out16.stride(0) if out16 is not None else 0)

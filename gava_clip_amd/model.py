@@ -845,12 +845,27 @@ class VitaCLIP(nn.Module, _HipHost):
 
     def _gather(self, feats):
         """RCCL all-gather over xGMI of the per-clip embeddings (north_star): each rank
-        holds whole clips, every rank ends with the embeddings (and logits) of the global batch."""
+        holds whole clips, every rank ends with the embeddings (and logits) of the global batch.
+        Contract: with an initialised process group of world size N and grad disabled, forward() returns
+        logits of shape (N*B, C), rank-major; `local_logits()` gives a rank its own B rows - what the reference's
+        evaluate() loops index with their local labels (training/train.py:661-670).  Under autograd nothing is gathered
+        (every rank keeps its own clips, as the reference's DDP does)."""
         import torch.distributed as dist
         if not (self.gather_across_ranks and dist.is_available() and dist.is_initialized()
                 and dist.get_world_size() > 1):
             return feats
         feats = feats.contiguous()
+        # all_gather_into_tensor needs the same number of rows on every rank: checked once per row count (a 1-int
+        # all-gather), so that a ragged last batch fails with a message instead of corrupting the gathered matrix
+        checked = self.__dict__.setdefault("_gather_checked", set())
+        if feats.shape[0] not in checked:
+            mine = torch.tensor([feats.shape[0]], dtype=torch.int64, device=feats.device if dist.get_backend() != "gloo" else "cpu")
+            rows = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(rows, mine)
+            if any(int(r) != feats.shape[0] for r in rows):
+                raise hip.GavaError(f"gather_across_ranks needs the same batch size on every rank, got {[int(r) for r in rows]}; "
+                                    "pad the last batch or set model.gather_across_ranks = False")
+            checked.add(feats.shape[0])
         if dist.get_backend() == "gloo" and feats.is_cuda:
             # CPU rendezvous (tests on a single-GPU box): stage through the host
             out = torch.empty(dist.get_world_size() * feats.shape[0], feats.shape[1], dtype=feats.dtype)
@@ -859,6 +874,14 @@ class VitaCLIP(nn.Module, _HipHost):
         out = torch.empty(dist.get_world_size() * feats.shape[0], feats.shape[1], dtype=feats.dtype, device=feats.device)
         dist.all_gather_into_tensor(out, feats)
         return out
+
+    def local_logits(self, logits):
+        """Rows of this rank in the gathered logits (identity when nothing was gathered)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return logits
+        b = logits.shape[0] // dist.get_world_size()
+        return logits if logits.shape[0] == self.last.get("local_batch", -1) else logits[dist.get_rank() * b:(dist.get_rank() + 1) * b]
 
     def _class_mean_matrix(self, device):
         """(n_prompts, n_cls) matrix with 1/count_c in the rows of class c's prompts: flat logits @ A = per-class means."""
@@ -907,6 +930,7 @@ class VitaCLIP(nn.Module, _HipHost):
     def _forward_impl(self, x, memory, video_nte, desc_wise):
         lib = hip.load()
         B, Cc, T, Hh, Ww = x.size()
+        self.last["local_batch"] = B
         sh = self._shape
         if not x.is_cuda:
             raise hip.GavaError("VitaCLIP (gava_clip_amd) runs on the HIP device only: move the model and the "

@@ -96,6 +96,13 @@ typedef struct {
    * caller runs on another stream beside this GEMM get CUs of their own (0 = use every CU).  Per call: the library keeps
    * no launch state between calls. */
   int cu_reserve;
+  /* LayerNorm folding without the gava_row_stats launch in between (big-M GEMMs: the persistent kernel only; N % 256 == 0,
+   * N <= 1024; anything else is rejected, never silently routed to another path).  Producer: rowsum_reduced != 0 makes
+   * rowsum_out float2 [ceil(M/256)*256][4] - slot n/256 of row m holds (sum x, sum x^2) over columns [256*(n/256), +256),
+   * the four waves' partials added in a fixed order.  Consumer: fold_partials = that array (instead of fold_stats); the
+   * kernel derives (mean, rstd) of its rows itself (eps 1e-5, variance = E[x^2] - mean^2, fixed summation order). */
+  int rowsum_reduced;
+  const float* fold_partials;
 } gava_gemm_args;
 int gava_gemm(const gava_gemm_args* a, gava_stream_t stream);
 
@@ -110,6 +117,11 @@ typedef struct {
   float* out32; int64_t out32_stride;    /* may be NULL; may alias in */
   int rows, D, prec;
   int split_out;                         /* out16 row = [hi(D) | lo(D) | hi(D)], see gava_gemm_args */
+  /* Optional second LayerNorm applied to the first one's fp32 result in the same pass (both NULL = off): out32 then
+   * receives LN(in; gamma, beta) and out16 receives LN(LN(in; gamma, beta); gamma2, beta2).  ln_pre followed by norm1 of
+   * block 0 (VitaCLIP_vision_encoder.py:113, VitaCLIP_vision_encoder_utils.py:190): one read of the embedding instead
+   * of two row passes. */
+  const float* gamma2; const float* beta2;
 } gava_layernorm_args;
 int gava_layernorm(const gava_layernorm_args* a, gava_stream_t stream);
 

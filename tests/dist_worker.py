@@ -13,7 +13,13 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 def _init(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("GAVA_TEST_BACKEND", "gloo") == "nccl":
+        # one process per GPU over RCCL, as bench.py and a real node run it (needs >= world devices)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
 def gather_cpu(rank, world, port, out_dir):

@@ -113,6 +113,16 @@ def test_layernorm(prec, rows, D):
     c = torch.zeros(rows, D, dtype=hip.h16_dtype(prec), device=d)
     hip.layernorm(x, None, None, out16=c, prec=prec)
     assert torch.equal(c, x.to(c.dtype))
+    # two LayerNorms in one row pass (ln_pre + norm1 of block 0): out32 = first, out16 = second applied to the first;
+    # bit-identical to two separate launches, also in place
+    g2, b2 = (1 + rnd((D,), 0.1, 4)).to(d), rnd((D,), 0.1, 5).to(d)
+    sep16 = torch.zeros(rows, D, dtype=hip.h16_dtype(prec), device=d)
+    hip.layernorm(o32, g2, b2, out16=sep16, prec=prec)
+    x3, f16 = x.clone(), torch.zeros(rows, D, dtype=hip.h16_dtype(prec), device=d)
+    hip.layernorm(x3, g, b, out16=f16, out32=x3, prec=prec, gamma2=g2, beta2=b2)
+    assert torch.equal(x3, o32) and torch.equal(f16, sep16)
+    with pytest.raises(hip.GavaError):
+        hip.layernorm(x, g, b, out16=f16, prec=prec, gamma2=g2, beta2=b2)      # needs out32 for the first result
 
 
 def attn_ref(q, k, v, causal):
@@ -336,3 +346,60 @@ def test_layernorm_folded_into_the_next_gemm(prec, M, K_prod):
         else:
             full = full * torch.sigmoid(1.702 * full)
         assert (out.float() - full).abs().max() < 40 * EPS16[prec] * full.abs().max()
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,D", [(45000, 768), (20000, 1024), (300, 768)])
+def test_layernorm_folding_without_the_row_stats_launch(prec, M, D):
+    """rowsum_reduced / fold_partials (gava_hip.h): the persistent producer pre-reduces its (sum, sum^2) per 256-column tile
+    (a fixed-order sum of its four waves' partials, exchanged through LDS) and the persistent consumer derives (mean, rstd)
+    of its rows itself - same results as the three-launch form (producer, gava_row_stats, consumer) up to the summation
+    order of the statistics, and deterministic.  M = 300: a single ragged tile; D = 1024: four slots (ViT-L/14)."""
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    Kp = 768
+    A = rnd((M, Kp), 1.0, 1).to(d).to(dt)
+    Wp = rnd((D, Kp), Kp ** -0.5, 2).to(d).to(dt)
+    bp = rnd((D,), 0.3, 3).to(d)
+    X0 = (rnd((M, D), 1.0, 4) + 0.7).to(d)            # a non-zero mean, so that E[x^2] - mean^2 is exercised
+    Mp = (M + 255) // 256 * 256
+    X = X0.clone()
+    x16 = torch.zeros(Mp, D, dtype=dt, device=d)
+    part = torch.full((Mp + 32, 4, 2), float("nan"), dtype=torch.float32, device=d)   # unwritten slots must never be read
+    hip.gemm(A, Wp, bp, X, epilogue=hip.EPI_F32, prec=prec, resid=X, x16_out=x16, rowsum_out=part, rowsum_reduced=True)
+    slots = D // 256
+    assert torch.isfinite(part[:M, :slots]).all()
+    assert torch.allclose(part[:M, :slots, 0].sum(1), X.sum(1), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(part[:M, :slots, 1].sum(1), (X * X).sum(1), rtol=1e-4, atol=2e-3)
+    # the three-launch form on the same inputs
+    X2, x16b = X0.clone(), torch.zeros(Mp, D, dtype=dt, device=d)
+    rowsum = torch.zeros(Mp, D // 64, 2, dtype=torch.float32, device=d)
+    hip.gemm(A, Wp, bp, X2, epilogue=hip.EPI_F32, prec=prec, resid=X2, x16_out=x16b, rowsum_out=rowsum)
+    assert torch.equal(X, X2) and torch.equal(x16, x16b)
+    stats = hip.row_stats(rowsum, D)
+    gamma, beta = (1 + rnd((D,), 0.2, 5)).to(d), rnd((D,), 0.2, 6).to(d)
+    for N, epi in ((3 * D, hip.EPI_H16), (4 * D, hip.EPI_H16_QGELU)):
+        W = rnd((N, D), D ** -0.5, 7).to(d)
+        b = rnd((N,), 0.3, 8).to(d)
+        Wf = (W * gamma).to(dt)
+        fs, ft = Wf.float().sum(1).contiguous(), (W @ beta + b).contiguous()
+        kw = dict(scale_cols=N // 3, scale=0.125) if epi == hip.EPI_H16 else {}
+        a = torch.zeros(M, N, dtype=dt, device=d)
+        b1 = torch.zeros(M, N, dtype=dt, device=d)
+        b2 = torch.zeros(M, N, dtype=dt, device=d)
+        hip.gemm(x16[:M], Wf, None, a, epilogue=epi, prec=prec, fold_stats=stats, fold_s=fs, fold_t=ft, **kw)
+        hip.gemm(x16[:M], Wf, None, b1, epilogue=epi, prec=prec, fold_partials=part, fold_s=fs, fold_t=ft, **kw)
+        hip.gemm(x16[:M], Wf, None, b2, epilogue=epi, prec=prec, fold_partials=part, fold_s=fs, fold_t=ft, **kw)
+        assert torch.equal(b1, b2)
+        tol = 4 * EPS16[prec]
+        assert torch.allclose(a.float(), b1.float(), rtol=tol, atol=tol * 2), (N, epi)
+        full = torch.nn.functional.layer_norm(X, (D,), gamma, beta) @ W.t() + b
+        if epi == hip.EPI_H16:
+            full[:, :N // 3] *= 0.125
+        else:
+            full = full * torch.sigmoid(1.702 * full)
+        assert float((b1.float() - full).abs().max()) < 40 * EPS16[prec] * float(full.abs().max())
+    # only the persistent kernel implements the mode: a shape it does not take is rejected, not routed elsewhere
+    with pytest.raises(hip.GavaError):
+        hip.gemm(A[:, :128].contiguous(), rnd((128, 128), 0.1, 9).to(d).to(dt), None, torch.zeros(M, 128, dtype=dt, device=d),
+                 epilogue=hip.EPI_H16, prec=prec, fold_partials=part, fold_s=fs[:128].contiguous(), fold_t=ft[:128].contiguous())

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Per-stage cycle shares of the persistent GEMM (v3) from in-kernel s_memtime stamps: vmcnt wait, barrier wait, stage
-body and epilogue, per wave group (gava_debug_set_buffer; no stamp executes in the product path)."""
+body and epilogue, per wave group (gava_debug_set_buffer).  The stamps are compiled in only with -DGAVA_STAMPS (they cost
+scalar registers the product kernels need): build the variant first,
+    tools/ab_build.sh stamps -DGAVA_STAMPS  &&  GAVA_HIP_LIB=gava_clip_amd/libgava_hip_stamps.so python tools/gemm_stamps.py fc2"""
 import ctypes as C, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -19,12 +21,25 @@ if which == "fc2":
 elif which == "qkv":
     A, W, b, O = rn(R, D), rn(3 * D, D, scale=D ** -0.5), rn(3 * D, dtype=torch.float32), torch.empty(R, 3 * D, dtype=torch.float16, device="cuda")
     fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_H16, prec=0, scale_cols=D, scale=0.125)
-elif which == "fc1fold":   # fc1 with LayerNorm folded in (consumer side)
+elif which in ("fc1fold", "qkvfold"):   # consumers with LayerNorm folded in
+    N = F if which == "fc1fold" else 3 * D
     Rp = (R + 255) // 256 * 256
-    A, W, O = rn(R, D), rn(F, D, scale=D ** -0.5), torch.empty(R, F, dtype=torch.float16, device="cuda")
+    A, W, O = rn(R, D), rn(N, D, scale=D ** -0.5), torch.empty(R, N, dtype=torch.float16, device="cuda")
     st = torch.cat([rn(Rp, 1, scale=0.1, dtype=torch.float32), 1 + rn(Rp, 1, scale=0.1, dtype=torch.float32).abs()], 1).contiguous()
-    fs_, ft_ = W.float().sum(1).contiguous(), rn(F, dtype=torch.float32)
-    fn = lambda: hip.gemm(A, W, None, O, epilogue=hip.EPI_H16_QGELU, prec=0, fold_stats=st, fold_s=fs_, fold_t=ft_)
+    fs_, ft_ = W.float().sum(1).contiguous(), rn(N, dtype=torch.float32)
+    if which == "fc1fold":
+        fn = lambda: hip.gemm(A, W, None, O, epilogue=hip.EPI_H16_QGELU, prec=0, fold_stats=st, fold_s=fs_, fold_t=ft_)
+    else:
+        fn = lambda: hip.gemm(A, W, None, O, epilogue=hip.EPI_H16, prec=0, scale_cols=D, scale=0.125, fold_stats=st, fold_s=fs_, fold_t=ft_)
+elif which in ("outfold", "fc2fold", "out"):
+    K = F if which == "fc2fold" else D
+    Rp = (R + 255) // 256 * 256
+    A, W, b, O = rn(R, K), rn(D, K, scale=K ** -0.5), rn(D, dtype=torch.float32), rn(R, D, dtype=torch.float32)
+    x16, rsum = torch.empty(Rp, D, dtype=torch.float16, device="cuda"), torch.empty(Rp, D // 64, 2, dtype=torch.float32, device="cuda")
+    if which == "out":
+        fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32, prec=0, resid=O)
+    else:
+        fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32, prec=0, resid=O, x16_out=x16, rowsum_out=rsum)
 else:
     A, W, b, O = rn(R, D), rn(F, D, scale=D ** -0.5), rn(F, dtype=torch.float32), torch.empty(R, F, dtype=torch.float16, device="cuda")
     fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_H16_QGELU, prec=0)

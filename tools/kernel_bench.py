@@ -43,6 +43,21 @@ elif a.which == "qkv":
 elif a.which == "out":
     A, W, b, O = rn(R, D), rn(D, D, scale=D ** -0.5), rn(D, dtype=torch.float32), rn(R, D, dtype=torch.float32)
     fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32, prec=prec, resid=O); fl = 2.0 * R * D * D
+elif a.which in ("fc1part", "qkvpart"):      # consumers that derive (mean, rstd) from the producers' partials themselves
+    N = F if a.which == "fc1part" else 3 * D
+    Rp = (R + 255) // 256 * 256
+    A, W, O = rn(R, D), rn(N, D, scale=D ** -0.5), torch.empty(R, N, dtype=dt, device=d)
+    part = torch.rand(Rp + 32, 4, 2, dtype=torch.float32, device=d, generator=g) * 40 + 200
+    fs, ft = W.float().sum(1).contiguous(), rn(N, dtype=torch.float32)
+    epi = hip.EPI_H16_QGELU if a.which == "fc1part" else hip.EPI_H16
+    kw = {} if a.which == "fc1part" else dict(scale_cols=D, scale=0.125)
+    fn = lambda: hip.gemm(A, W, None, O, epilogue=epi, prec=prec, fold_partials=part, fold_s=fs, fold_t=ft, **kw); fl = 2.0 * R * N * D
+elif a.which in ("fc2part", "outpart"):      # producers with the row sums pre-reduced per 256-column tile
+    K = F if a.which == "fc2part" else D
+    Rp = (R + 255) // 256 * 256
+    A, W, b, O = rn(R, K), rn(D, K, scale=K ** -0.5), rn(D, dtype=torch.float32), rn(R, D, dtype=torch.float32)
+    x16, part = torch.empty(Rp, D, dtype=dt, device=d), torch.empty(Rp + 32, 4, 2, dtype=torch.float32, device=d)
+    fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32, prec=prec, resid=O, x16_out=x16, rowsum_out=part, rowsum_reduced=True); fl = 2.0 * R * K * D
 elif a.which in ("fc1fold", "qkvfold"):      # consumers of the LayerNorm folding
     N = F if a.which == "fc1fold" else 3 * D
     Rp = (R + 255) // 256 * 256
