@@ -208,7 +208,7 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
                                          float* debug_cls, float* saved_x, void* workspace, size_t workspace_bytes,
                                          gava_stream_t stream) {
   TRY(check_vision(m));
-  if (!x || !cls_x || !summary || !workspace) return GAVA_EINVAL;
+  if ((!x && !m->clips) || !cls_x || !summary || !workspace) return GAVA_EINVAL;
   const VisionWs w = carve_vision(m, workspace, workspace_bytes);
   if (w.total > workspace_bytes) return GAVA_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
@@ -226,7 +226,8 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
   {
     // im2col-free patch embedding: the GEMM builds its A tiles straight from the frames
     gava_gemm_args a{};
-    a.A = nullptr; a.lda = Kp; a.frames = x; a.frame_size = m->size; a.patch = m->P;
+    a.A = nullptr; a.lda = Kp; a.frames = m->clips ? nullptr : x; a.frame_size = m->size; a.patch = m->P;
+    a.clips = m->clips; a.clip_lut = m->clip_lut;
     a.W = m->w_patch; a.ldw = Kp; a.bias = m->b_patch;
     a.out = w.X; a.ldo = D; a.M = BT * n; a.N = D; a.K = Kp; a.epilogue = GAVA_EPI_F32_PATCH; a.prec = pr;
     a.pos = m->pos_embed; a.time = m->time_embed; a.n_patches = n; a.T = m->T_in;
@@ -405,7 +406,7 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
                                         const gava_vision_saved* sv, void* workspace, size_t workspace_bytes,
                                         gava_stream_t stream) {
   TRY(check_vision(m));
-  if (!x || !cls_x || !summary || !workspace || !sv || !sv->e0 || !sv->x || !sv->x1 || !sv->qkv || !sv->pre || !sv->sidekv)
+  if ((!x && !m->clips) || !cls_x || !summary || !workspace || !sv || !sv->e0 || !sv->x || !sv->x1 || !sv->qkv || !sv->pre || !sv->sidekv)
     return GAVA_EINVAL;
   const VisionWs w = carve_vision(m, workspace, workspace_bytes);
   if (w.total > workspace_bytes) return GAVA_EWORKSPACE;
@@ -420,7 +421,8 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
   const size_t RD = (size_t)R * D;
   {
     gava_gemm_args a{};
-    a.A = nullptr; a.lda = Kp; a.frames = x; a.frame_size = m->size; a.patch = m->P;
+    a.A = nullptr; a.lda = Kp; a.frames = m->clips ? nullptr : x; a.frame_size = m->size; a.patch = m->P;
+    a.clips = m->clips; a.clip_lut = m->clip_lut;
     a.W = m->w_patch; a.ldw = Kp; a.bias = m->b_patch;
     a.out = sv->e0; a.ldo = D; a.M = BT * n; a.N = D; a.K = Kp; a.epilogue = GAVA_EPI_F32_PATCH; a.prec = pr;
     a.pos = m->pos_embed; a.time = m->time_embed; a.n_patches = n; a.T = m->T_in;

@@ -16,6 +16,7 @@
 //   * workgroup -> tile map: each XCD (private 4 MiB L2) walks a contiguous range of tiles, and
 //     inside it tiles are ordered in SM x SN super-tiles whose operand panels fit that L2.
 #include "common.h"
+#include "clip_pixel.h"
 #include "internal.h"
 #include <stdlib.h>
 #include <stdio.h>
@@ -62,6 +63,7 @@ struct GemmParams {
   int scale_cols; float scale;
   const float* pos; const float* time; int n_patches; int T;
   const float* frames; int fsize; int patch;   // im2col-free patch A operand (EPI_F32_PATCH, A == nullptr)
+  const gava_clip_desc* clips; const float* clut;   // ... from decoded uint8 frames (gava_clip_desc, fp32 [3][256] table)
   int tiles_m, tiles_n, n_tiles;
   int split_out;
   int sm, sn;   // super-tile shape (in tiles)
@@ -109,7 +111,7 @@ void gemm_kernel(const GemmParams p) {
   }
   const int m0 = mt * BM, n0 = nt * BN;
 
-  const bool direct = EPI == GAVA_EPI_F32_PATCH && p.frames != nullptr;
+  const bool direct = EPI == GAVA_EPI_F32_PATCH && (p.frames != nullptr || p.clips != nullptr);
   // ---- per-lane source pointers of this wave's staging pieces (swizzle on the source side)
   const unsigned short* src[PPW];
 #pragma unroll
@@ -152,7 +154,24 @@ void gemm_kernel(const GemmParams p) {
       const int b = frame / p.T, t = frame - b * p.T;
       const int py = pp / g, px = pp - py * g;
       const int k = kt * BK + chunk * 8;
-      if ((p.patch & 7) == 0 && k + 8 <= Kreal) {
+      if (EPI == GAVA_EPI_F32_PATCH && p.clips) {
+        // uint8 source: every element is one pixel of the (virtual) preprocessed clip - temporal crop, normalisation,
+        // bilinear resize and centre crop evaluated here (clip_pixel.h), nothing but the decoded frames is read from HBM
+        const gava_clip_desc& cd = p.clips[b];
+        int f = cd.t_st + t * cd.rate;
+        f = f < cd.n_frames ? f : cd.n_frames - 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int kq = k + q;
+          float v = 0.f;
+          if (kq < Kreal) {
+            const int c = kq / P2, rem = kq - c * P2, ky = rem / p.patch, kx = rem - ky * p.patch;
+            v = clip_pixel1(cd.frames, cd.height, cd.width, cd.h_st, cd.w_st, cd.scale_h, cd.scale_w, p.clut, 0.f, 1.f, f, c,
+                            py * p.patch + ky, px * p.patch + kx);
+          }
+          pe[ti][q] = v;
+        }
+      } else if ((p.patch & 7) == 0 && k + 8 <= Kreal) {
         const int c = k / P2, rem = k - c * P2, ky = rem / p.patch, kx = rem - ky * p.patch;
         const float* sp = p.frames + ((((long)b * 3 + c) * p.T + t) * p.fsize + (py * p.patch + ky)) * p.fsize + px * p.patch + kx;
         const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
@@ -950,13 +969,13 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   static const int variant = getenv("GAVA_GEMM_VARIANT") ? atoi(getenv("GAVA_GEMM_VARIANT")) : 0;
   if (gp.rowsum_reduced || gp.fpart) {   // only the persistent kernel implements these; never fall back silently
     const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
-    return (gp.N % 256 == 0 && fits && !gp.frames) ? launch_256<P, 3>(gp, epi, s) : GAVA_EINVAL;
+    return (gp.N % 256 == 0 && fits && !gp.frames && !gp.clips) ? launch_256<P, 3>(gp, epi, s) : GAVA_EINVAL;
   }
   // small-M problems (prompt path, text tower at few classes): 128x128 tiles fill more CUs;
   // the im2col-free patch loader lives in the templated kernel
   // im2col-free patch embedding: 128 x 256 tiles (8 waves) build every A tile for 3 instead of 6 N-tiles at D = 768
-  if (gp.frames && gp.N % 256 == 0 && variant != 1 && variant != 10) return launch_tile<P, 128, 256, 2>(gp, epi, s);
-  if (gp.frames || gp.M <= 2048 || variant == 1 || variant == 10) return launch_tile<P, 128, 128, 2>(gp, epi, s);
+  if ((gp.frames || gp.clips) && gp.N % 256 == 0 && variant != 1 && variant != 10) return launch_tile<P, 128, 256, 2>(gp, epi, s);
+  if (gp.frames || gp.clips || gp.M <= 2048 || variant == 1 || variant == 10) return launch_tile<P, 128, 128, 2>(gp, epi, s);
   if (variant == 2) return launch_tile<P, 256, 128, 3>(gp, epi, s);
   if (variant == 12 && gp.N % 256 == 0) return launch_tile<P, 128, 256, 2>(gp, epi, s);
   if (variant == 13 && gp.N % 256 == 0) return launch_tile<P, 128, 256, 3>(gp, epi, s);
@@ -977,16 +996,18 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
 }  // namespace
 
 extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
-  const bool patch_direct = a && a->epilogue == GAVA_EPI_F32_PATCH && !a->A && a->frames;
+  const bool patch_u8 = a && a->epilogue == GAVA_EPI_F32_PATCH && !a->A && !a->frames && a->clips;
+  const bool patch_direct = a && a->epilogue == GAVA_EPI_F32_PATCH && !a->A && (a->frames || patch_u8);
   if (!a || (!a->A && !patch_direct) || !a->W || !a->out) return GAVA_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return GAVA_EINVAL;
   if (a->N % 128 || a->K % BK) return GAVA_EINVAL;
   if (a->ldw % 8 || a->ldw < a->K) return GAVA_EINVAL;
   if (!patch_direct && (a->lda % 8 || a->lda < a->K)) return GAVA_EINVAL;
   if (patch_direct && (a->patch <= 0 || a->frame_size % a->patch || 3 * a->patch * a->patch > a->K ||
-                       (a->frame_size / a->patch) * (a->frame_size / a->patch) != a->n_patches || ((uintptr_t)a->frames & 15) ||
-                       ((a->patch & 7) == 0 && (a->frame_size & 3))))
+                       (a->frame_size / a->patch) * (a->frame_size / a->patch) != a->n_patches ||
+                       (!patch_u8 && (((uintptr_t)a->frames & 15) || ((a->patch & 7) == 0 && (a->frame_size & 3))))))
     return GAVA_EINVAL;
+  if (patch_u8 && !a->clip_lut) return GAVA_EINVAL;
   if (((uintptr_t)a->W | (uintptr_t)a->out) & 15) return GAVA_EINVAL;
   if (a->A && ((uintptr_t)a->A & 15)) return GAVA_EINVAL;
   if (a->bias && ((uintptr_t)a->bias & 15)) return GAVA_EINVAL;
@@ -1019,7 +1040,8 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.M = a->M; gp.N = a->N; gp.K = a->K;
   gp.scale_cols = a->scale_cols; gp.scale = a->scale;
   gp.pos = a->pos; gp.time = a->time; gp.n_patches = a->n_patches; gp.T = a->T;
-  gp.frames = patch_direct ? a->frames : nullptr; gp.fsize = a->frame_size; gp.patch = a->patch;
+  gp.frames = (patch_direct && !patch_u8) ? a->frames : nullptr; gp.fsize = a->frame_size; gp.patch = a->patch;
+  gp.clips = patch_u8 ? a->clips : nullptr; gp.clut = a->clip_lut;
   gp.split_out = a->split_out;
   gp.cu_reserve = a->cu_reserve;
 #ifdef GAVA_ENABLE_ABLATE   // timing-probe builds only (tools/ab_build.sh NAME -DGAVA_ENABLE_ABLATE): results are WRONG by design

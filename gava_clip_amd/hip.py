@@ -21,7 +21,7 @@ EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_text_forward", "gava_similarity_head", "gava_convert_h16", "gava_debug_set_buffer",
            "gava_preprocess_clip", "gava_layernorm_backward", "gava_qgelu_backward", "gava_attention_backward",
            "gava_text_forward_train", "gava_vision_forward_train", "gava_attention_backward_workspace_bytes", "gava_vision_forward_keep", "gava_row_stats",
-           "gava_probe_fc1_enable", "gava_probe_fc1_read"]
+           "gava_probe_fc1_enable", "gava_probe_fc1_read", "gava_clip_geometry"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 
@@ -36,7 +36,8 @@ class GemmArgs(C.Structure):
                 ("aux", _vp), ("aux_prec", C.c_int), ("aux_out", _vp),
                 ("x16_out", _vp), ("ld_x16", C.c_int64), ("rowsum_out", _fp),
                 ("fold_stats", _fp), ("fold_s", _fp), ("fold_t", _fp), ("cu_reserve", C.c_int),
-                ("rowsum_reduced", C.c_int), ("fold_partials", _fp)]
+                ("rowsum_reduced", C.c_int), ("fold_partials", _fp),
+                ("clips", _vp), ("clip_lut", _fp)]
 
 
 class LayerNormArgs(C.Structure):
@@ -56,6 +57,12 @@ class AttentionArgs(C.Structure):
                 ("q_batch_rows", C.c_int), ("ld_q", C.c_int64)]
 
 
+class ClipDesc(C.Structure):
+    _fields_ = [("frames", _vp), ("n_frames", C.c_int), ("height", C.c_int), ("width", C.c_int),
+                ("t_st", C.c_int), ("rate", C.c_int), ("h_st", C.c_int), ("w_st", C.c_int),
+                ("scale_h", C.c_float), ("scale_w", C.c_float)]
+
+
 class VisionLayer(C.Structure):
     _fields_ = [(n, _vp) for n in (
         "w_qkv", "b_qkv", "w_out", "b_out", "w_fc1", "b_fc1", "w_fc2", "b_fc2",
@@ -71,7 +78,8 @@ class VisionModel(C.Structure):
                 ("F", C.c_int), ("E", C.c_int), ("G", C.c_int), ("prec", C.c_int),
                 ("w_patch", _vp), ("b_patch", _fp), ("cls_token", _fp), ("pos_embed", _fp), ("time_embed", _fp),
                 ("lnpre_g", _fp), ("lnpre_b", _fp), ("lnpost_g", _fp), ("lnpost_b", _fp),
-                ("w_proj", _vp), ("layer", C.POINTER(VisionLayer))]
+                ("w_proj", _vp), ("layer", C.POINTER(VisionLayer)),
+                ("clips", _vp), ("clip_lut", _fp)]
 
 
 class TextLayer(C.Structure):
@@ -92,7 +100,7 @@ class PreprocessArgs(C.Structure):
                 ("mean", C.c_float * 3), ("std", C.c_float * 3),
                 ("T", C.c_int), ("rate", C.c_int), ("size", C.c_int),
                 ("out", _fp), ("out_stride_c", C.c_int64), ("out_stride_t", C.c_int64),
-                ("first_temporal_view", C.c_int), ("first_spatial_view", C.c_int)]
+                ("first_temporal_view", C.c_int), ("first_spatial_view", C.c_int), ("lut", _fp)]
 
 
 class VisionSaved(C.Structure):
@@ -168,6 +176,8 @@ def load():
     lib.gava_attention_backward.restype = C.c_int
     lib.gava_attention_backward_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.gava_attention_backward_workspace_bytes.restype = C.c_size_t
+    lib.gava_clip_geometry.argtypes = [C.POINTER(ClipDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.gava_clip_geometry.restype = C.c_int
     lib.gava_probe_fc1_enable.argtypes = [C.c_int]
     lib.gava_probe_fc1_read.argtypes = [C.POINTER(C.c_float), C.c_int]
     lib.gava_row_stats.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, _vp]
@@ -211,8 +221,9 @@ def h16_dtype(prec):
 def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0,
          pos=None, time=None, n_patches=0, T=0, M=None, split_out=False, frames=None, frame_size=0, patch=0, aux=None,
          aux_prec=None, aux_out=None, x16_out=None, rowsum_out=None, fold_stats=None, fold_s=None, fold_t=None,
-         cu_reserve=0, rowsum_reduced=False, fold_partials=None):
+         cu_reserve=0, rowsum_reduced=False, fold_partials=None, clips=None, clip_lut=None):
     a = GemmArgs()
+    a.clips, a.clip_lut = ptr(clips), ptr(clip_lut)
     a.cu_reserve = cu_reserve
     a.rowsum_reduced, a.fold_partials = int(rowsum_reduced), ptr(fold_partials)
     a.x16_out, a.ld_x16, a.rowsum_out = ptr(x16_out), (x16_out.stride(0) if x16_out is not None else 0), ptr(rowsum_out)
@@ -272,7 +283,15 @@ def convert_h16(x, prec):
     return out
 
 
-def preprocess_clip(frames_u8, out, *, T, rate, size, mean, std, first_temporal_view=False, first_spatial_view=False):
+def clip_lut(mean, std, device):
+    """fp32 [3][256] with (v/255 - mean[c]) / std[c] for every byte value, evaluated with the reference's own torch expression
+    (video_dataset/dataset.py:119,121) on the host: the GPU kernels look the normalised value up."""
+    v = torch.arange(256, dtype=torch.float32).view(1, 256) / 255.
+    lut = (v - torch.tensor(mean, dtype=torch.float32).view(3, 1)) / torch.tensor(std, dtype=torch.float32).view(3, 1)
+    return lut.contiguous().to(device)
+
+
+def preprocess_clip(frames_u8, out, *, T, rate, size, mean, std, first_temporal_view=False, first_spatial_view=False, lut=None):
     """frames_u8: uint8 [n][H][W][3] (device); out: fp32 view [3][T][size][size] whose last two dims are contiguous."""
     assert frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.shape[-1] == 3 and frames_u8.is_contiguous()
     assert out.dtype == torch.float32 and tuple(out.shape) == (3, T, size, size)
@@ -283,6 +302,7 @@ def preprocess_clip(frames_u8, out, *, T, rate, size, mean, std, first_temporal_
     a.T, a.rate, a.size = T, rate, size
     a.out, a.out_stride_c, a.out_stride_t = ptr(out), out.stride(0), out.stride(1)
     a.first_temporal_view, a.first_spatial_view = int(first_temporal_view), int(first_spatial_view)
+    a.lut = ptr(lut)
     check(load().gava_preprocess_clip(C.byref(a), stream_ptr()), "gava_preprocess_clip")
 
 
@@ -331,3 +351,17 @@ def row_stats(rowsum, D):
     stats = torch.empty(rows, 2, dtype=torch.float32, device=rowsum.device)
     check(load().gava_row_stats(ptr(rowsum), slots, D, rows, ptr(stats), stream_ptr()), "gava_row_stats")
     return stats
+
+
+def clip_descriptors(videos, *, T, rate, size, first_temporal_view=False, first_spatial_view=False):
+    """uint8 videos [n_i][H_i][W_i][3] on the device -> (uint8 device tensor holding an array of gava_clip_desc, keep-alive
+    list).  The geometry is computed by the library (gava_clip_geometry: dataset.py:124-129,163-186)."""
+    lib = load()
+    arr = (ClipDesc * len(videos))()
+    for i, v in enumerate(videos):
+        assert v.is_cuda and v.dtype == torch.uint8 and v.dim() == 4 and v.shape[-1] == 3 and v.is_contiguous()
+        arr[i].frames, arr[i].n_frames, arr[i].height, arr[i].width = ptr(v), v.shape[0], v.shape[1], v.shape[2]
+        check(lib.gava_clip_geometry(C.byref(arr[i]), T, rate, size, int(first_temporal_view), int(first_spatial_view)),
+              "gava_clip_geometry")
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(videos[0].device), list(videos)

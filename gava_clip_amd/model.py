@@ -555,18 +555,24 @@ class _HipHost:
         return ws
 
     # ---- encoders -----------------------------------------------------------------------------
-    def encode_video(self, x, saved=None, kept=None):
+    def encode_video(self, x, saved=None, kept=None, clips=None):
         """CLIPVisionEncoder.forward on the HIP path -> (cls_x (B,E), summary (B,D)), fp32.
         saved: optional fp32 [layers+2, B*T*(n+1), D] that receives what the backward recomputes from;
-        kept: optional dict of per-block activation buffers (training.alloc_kept) filled by gava_vision_forward_keep."""
-        if not x.is_cuda:
+        kept: optional dict of per-block activation buffers (training.alloc_kept) filled by gava_vision_forward_keep;
+        clips: instead of x, the decoded uint8 videos as (descriptor tensor, B, T, normalisation table, device) - the patch embedding
+        then reads the frames themselves (hip.clip_descriptors)."""
+        if clips is None and not x.is_cuda:
             raise hip.GavaError("VitaCLIP (gava_clip_amd) runs on the HIP device only: move the model and the "
                                 "input with .cuda(); there is no CPU fallback")
         lib = hip.load()
         pk, sh = self._pack(), self._shape
-        B, Cc, T, Hh, Ww = x.shape
-        assert Cc == 3 and Hh == sh["size"] and Ww == sh["size"], "input must be (B,3,T,size,size)"
-        x = x.detach().float().contiguous()
+        if clips is not None:
+            desc, B, T, lut, dev = clips
+            x = desc            # only its device is used below
+        else:
+            B, Cc, T, Hh, Ww = x.shape
+            assert Cc == 3 and Hh == sh["size"] and Ww == sh["size"], "input must be (B,3,T,size,size)"
+            x = x.detach().float().contiguous()
         te = self.visual.time_embed.detach().float()
         if T != te.size(0):  # VitaCLIP_vision_encoder.py:91-95
             te = F.interpolate(te.unsqueeze(0).transpose(1, 2), size=(T), mode='nearest').transpose(1, 2).squeeze(0)
@@ -580,6 +586,8 @@ class _HipHost:
             setattr(m, k, val)
         m.time_embed = C.c_void_p(te.data_ptr())
         m.layer = C.cast(pk["vis_layers"], C.POINTER(hip.VisionLayer))
+        if clips is not None:
+            m.clips, m.clip_lut = hip.ptr(desc), hip.ptr(lut)
         nbytes = lib.gava_vision_workspace_bytes(C.byref(m))
         if nbytes == 0:
             raise hip.GavaError(f"unsupported vision shape: B={B} T={T} num_frames={self.num_frames} {sh}")
@@ -593,10 +601,10 @@ class _HipHost:
                 sv = hip.VisionSaved(hip.ptr(kept["e0"]), hip.ptr(kept["x"]), hip.ptr(kept["x1"]), hip.ptr(kept["qkv"]),
                                      hip.ptr(kept["pre"]), hip.ptr(kept["sidekv"]), hip.ptr(kept.get("last_q")),
                                      hip.ptr(kept.get("last_x1")), hip.ptr(kept.get("last_pre")))
-                hip.check(lib.gava_vision_forward_keep(C.byref(m), hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), C.byref(sv),
+                hip.check(lib.gava_vision_forward_keep(C.byref(m), None if clips is not None else hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), C.byref(sv),
                                                        hip.ptr(ws), ws.numel(), hip.stream_ptr(x.device)), "gava_vision_forward_keep")
             else:
-                hip.check(lib.gava_vision_forward_train(C.byref(m), hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), hip.ptr(dbg),
+                hip.check(lib.gava_vision_forward_train(C.byref(m), None if clips is not None else hip.ptr(x), hip.ptr(cls_x), hip.ptr(summary), hip.ptr(dbg),
                                                         hip.ptr(saved), hip.ptr(ws), ws.numel(), hip.stream_ptr(x.device)),
                           "gava_vision_forward")
         self.last["cls_rows"] = dbg
@@ -927,9 +935,32 @@ class VitaCLIP(nn.Module, _HipHost):
         with torch.cuda.device(x.device):
             return self._forward_impl(x, memory, video_nte, desc_wise)
 
-    def _forward_impl(self, x, memory, video_nte, desc_wise):
+    def forward_frames(self, videos, preprocessor, memory=None, video_nte=None, desc_wise=False):
+        """forward() on DECODED videos instead of a preprocessed batch: `videos` is a list of uint8 device tensors
+        [n_i, H_i, W_i, 3] (PyAV's to_rgb().to_ndarray() order), `preprocessor` a gava_clip_amd.preprocess.ClipPreprocessor
+        (the evaluation branch of video_dataset/dataset.py:117-139).  The patch-embedding GEMM reads the frames themselves
+        (temporal crop, normalisation, bilinear resize and centre crop per loaded pixel): same logits, bit for bit, as
+        forward(preprocessor.batch(videos)), without the fp32 clip ever being written to HBM - 4x fewer input bytes.
+        Inference only (the training branch of the reference's data path augments on the host)."""
+        if torch.is_grad_enabled():
+            raise hip.GavaError("forward_frames is the evaluation data path: call it under torch.no_grad()")
+        pre = preprocessor
+        assert pre.spatial_size == self._shape["size"], "the preprocessor's crop size must be the model's input size"
+        dev = videos[0].device
+        with torch.cuda.device(dev):
+            pre.check(videos)
+            desc, keep = hip.clip_descriptors(videos, T=pre.num_frames, rate=pre.sampling_rate, size=pre.spatial_size,
+                                              first_temporal_view=pre.num_temporal_views > 1,
+                                              first_spatial_view=pre.num_spatial_views == 3)
+            clips = (desc, len(videos), pre.num_frames, pre.lut(dev), dev)
+            return self._forward_impl(desc, memory, video_nte, desc_wise, clips=clips)
+
+    def _forward_impl(self, x, memory, video_nte, desc_wise, clips=None):
         lib = hip.load()
-        B, Cc, T, Hh, Ww = x.size()
+        if clips is not None:
+            B, T = clips[1], clips[2]
+        else:
+            B, Cc, T, Hh, Ww = x.size()
         self.last["local_batch"] = B
         sh = self._shape
         if not x.is_cuda:
@@ -987,7 +1018,7 @@ class VitaCLIP(nn.Module, _HipHost):
             from .training import VisionTowerFn
             cls_x, summary = VisionTowerFn.apply(self, x, *[p for _, p in self._vision_trainables()])
         else:
-            cls_x, summary = self.encode_video(x)
+            cls_x, summary = self.encode_video(x, clips=clips)
         if text_stream is not None:
             torch.cuda.current_stream(x.device).wait_stream(text_stream)
             text.record_stream(torch.cuda.current_stream(x.device))

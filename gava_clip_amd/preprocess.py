@@ -32,6 +32,17 @@ class ClipPreprocessor:
         self.num_frames, self.sampling_rate, self.spatial_size = num_frames, sampling_rate, spatial_size
         self.mean = tuple(float(v) for v in torch.as_tensor(mean).flatten().tolist())
         self.std = tuple(float(v) for v in torch.as_tensor(std).flatten().tolist())
+        self._lut = {}
+
+    def lut(self, device):
+        """(v/255 - mean) / std for the 256 byte values per channel, the reference's expression evaluated once on the host"""
+        if device not in self._lut:
+            self._lut[device] = hip.clip_lut(self.mean, self.std, device)
+        return self._lut[device]
+
+    def check(self, videos):
+        for v in videos:
+            self._check(v)
 
     def _check(self, frames):
         if not frames.is_cuda:
@@ -53,7 +64,8 @@ class ClipPreprocessor:
         if out is None:
             out = torch.empty(3, T, S, S, dtype=torch.float32, device=frames.device)
         hip.preprocess_clip(frames.contiguous(), out, T=T, rate=self.sampling_rate, size=S, mean=self.mean, std=self.std,
-                            first_temporal_view=self.num_temporal_views > 1, first_spatial_view=self.num_spatial_views == 3)
+                            first_temporal_view=self.num_temporal_views > 1, first_spatial_view=self.num_spatial_views == 3,
+                            lut=self.lut(frames.device))
         return out
 
     def batch(self, videos):

@@ -57,6 +57,20 @@ int gava_probe_fc1_read(float* ms, int cap);
  * VitaCLIP_text_encoder.py:73-77 and the projections inside nn.MultiheadAttention :71).
  * Requirements: N % 128 == 0, K % 64 == 0, lda/ldw multiples of 8 elements, 16-byte aligned
  * pointers.  M is arbitrary. */
+/* One decoded video for the fused input path: the patch-embedding GEMM builds its A tiles straight from
+ * the uint8 RGB frames [n_frames][height][width][3] - temporal crop, (u8/255 - mean)/std, bilinear short-side resize and
+ * centre crop of video_dataset/dataset.py:117-139 are evaluated per loaded pixel, with the arithmetic of
+ * gava_preprocess_clip (bit-identical values), and the fp32 clip is never written to HBM.  gava_clip_geometry() fills the
+ * derived fields from the video's size.  Device array, one entry per clip of the batch. */
+typedef struct {
+  const uint8_t* frames; int n_frames, height, width;
+  int t_st, rate;                   /* frame(t) = min(t_st + t*rate, n_frames-1)                    */
+  int h_st, w_st;                   /* crop offset inside the resized frame                          */
+  float scale_h, scale_w;           /* source / resized extent (align_corners = False)               */
+} gava_clip_desc;
+/* host helper: the integer / float geometry of dataset.py:124-129,163-186 for one video; 0 on success */
+int gava_clip_geometry(gava_clip_desc* d, int T, int rate, int size, int first_temporal_view, int first_spatial_view);
+
 typedef struct {
   const void* A; int64_t lda;       /* h16 [M][lda]                                    */
   const void* W; int64_t ldw;       /* h16 [N][ldw]                                    */
@@ -103,6 +117,10 @@ typedef struct {
    * kernel derives (mean, rstd) of its rows itself (eps 1e-5, variance = E[x^2] - mean^2, fixed summation order). */
   int rowsum_reduced;
   const float* fold_partials;
+  /* EPI_F32_PATCH with A == NULL and frames == NULL: the uint8 source (see gava_clip_desc): clips = device array
+   * [M / (n_patches * T)], frame_size = the crop size, clip_lut = device fp32 [3][256]: lut[c][v] = (v/255 - mean[c]) / std[c]
+   * as the caller's fp32 arithmetic gives it (the reference's own torch expression: the normalisation is then exact). */
+  const gava_clip_desc* clips; const float* clip_lut;
 } gava_gemm_args;
 int gava_gemm(const gava_gemm_args* a, gava_stream_t stream);
 
@@ -188,6 +206,8 @@ typedef struct {
   const void* w_proj;                          /* visual.proj transposed, split-packed: [E][3D] =
                                                   [W_hi | W_hi | W_lo] h16 (see gava_gemm_args)  */
   const gava_vision_layer* layer;              /* host array [layers]                         */
+  /* optional uint8 input (gava_gemm_args.clips): when clips != NULL the drivers' `x` argument is ignored (may be NULL) */
+  const gava_clip_desc* clips; const float* clip_lut;   /* fp32 [3][256], see gava_gemm_args */
 } gava_vision_model;
 
 /* CLIPVisionEncoder.forward (VitaCLIP_vision_encoder.py:102-132).
@@ -350,6 +370,9 @@ typedef struct {
    * :136-139): with more than one temporal view that is the crop starting at frame 0 (:171-172), with three spatial
    * views the top / left one (:188-199).  first_temporal_view / first_spatial_view != 0 select those; 0 = centred. */
   int first_temporal_view, first_spatial_view;
+  /* optional device table fp32 [3][256] with (v/255 - mean[c]) / std[c] for every byte value (see gava_gemm_args.clip_lut):
+   * when given, the kernel looks the normalised value up instead of dividing - the same bits as the fused uint8 patch loader */
+  const float* lut;
 } gava_preprocess_args;
 int gava_preprocess_clip(const gava_preprocess_args* a, gava_stream_t stream);
 

@@ -102,3 +102,69 @@ def test_gpu_preprocess_first_of_many_views(n, h, w, views):
                            num_spatial_views=views[0], num_temporal_views=views[1])
     got = pre(v.cuda()).cpu()
     assert (got - ref).abs().max().item() <= 6e-6
+
+
+# ---- the fused input path: the patch-embedding GEMM reads the decoded uint8 frames itself ------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,patch,T,rate,shapes", [
+    (64, 16, 4, 2, [(9, 80, 120), (5, 100, 70), (12, 64, 64)]),     # P % 8 == 0
+    (56, 14, 2, 1, [(3, 60, 90), (2, 57, 56)]),                      # ViT-L/14's patch: K = 588 padded to 640
+])
+def test_patch_embedding_reads_uint8_frames(size, patch, T, rate, shapes):
+    """A tiles built from the decoded uint8 videos (temporal crop, normalisation, bilinear resize, centre crop per loaded
+    pixel) == the two-step form (gava_preprocess_clip writes the fp32 clip, the im2col-free GEMM reads it), bit for bit;
+    videos of different sizes in one batch."""
+    from gava_clip_amd import hip
+    from gava_clip_amd.preprocess import ClipPreprocessor
+    d = torch.device("cuda")
+    vids = [_video(n, h, w, 10 + i).to(d) for i, (n, h, w) in enumerate(shapes)]
+    pre = ClipPreprocessor(num_frames=T, sampling_rate=rate, spatial_size=size, mean=MEAN, std=STD)
+    x = pre.batch(vids)
+    B, D = len(vids), 256
+    g = size // patch
+    n, K = g * g, 3 * patch * patch
+    Kp = (K + 63) // 64 * 64
+    gen = torch.Generator().manual_seed(3)
+    W = torch.zeros(D, Kp)
+    W[:, :K] = torch.randn(D, K, generator=gen) * K ** -0.5
+    W16 = W.to(d).half()
+    bias, pos, tim = (torch.randn(s_, generator=gen).to(d) for s_ in ((D,), (n + 1, D), (T, D)))
+    outs = []
+    desc, keep = hip.clip_descriptors(vids, T=T, rate=rate, size=size)
+    for kw in (dict(frames=x), dict(clips=desc, clip_lut=pre.lut(d))):
+        X = torch.zeros(B * T * (n + 1), D, device=d)
+        hip.gemm(None, W16, bias, X, epilogue=hip.EPI_F32_PATCH, prec=hip.PREC_F16, pos=pos, time=tim, n_patches=n, T=T,
+                 M=B * T * n, frame_size=size, patch=patch, **kw)
+        outs.append(X)
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[0].abs().max()) > 0.1
+
+
+@pytest.mark.gpu
+def test_forward_frames_equals_forward_of_the_preprocessed_batch():
+    """VitaCLIP.forward_frames(videos, preprocessor) == forward(preprocessor.batch(videos)) bit for bit, and both meet the
+    oracle pipeline (CPU restatement of dataset.py:117-139 followed by the forward oracle) within 1e-3."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import CLASSES_3, model_kwargs, synth_torch_state, rel_to_max
+    from gava_clip_amd import VitaCLIP, hip
+    from gava_clip_amd.config import TINY
+    from gava_clip_amd.preprocess import ClipPreprocessor
+    from oracle.vita_oracle import Oracle
+    sd = synth_torch_state(TINY, 3)
+    m = VitaCLIP(**model_kwargs(TINY, CLASSES_3))
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    vids_cpu = [_video(11, 90, 130, 21), _video(6, 120, 80, 22)]
+    vids = [v.cuda() for v in vids_cpu]
+    pre = ClipPreprocessor(num_frames=TINY.num_frames, sampling_rate=2, spatial_size=TINY.input_size, mean=MEAN, std=STD)
+    with torch.no_grad():
+        a = m.forward_frames(vids, pre)[0]
+        b = m(pre.batch(vids))[0]
+    assert torch.equal(a, b)
+    x_ref = torch.stack([po.preprocess_clip(v, TINY.num_frames, 2, TINY.input_size, MEAN, STD) for v in vids_cpu])
+    want = Oracle(TINY, sd, torch.cat(m.tokenized_prompts)).forward(x_ref)["logits"].numpy()
+    assert rel_to_max(a.cpu().numpy(), want) < 1e-3
+    with pytest.raises(hip.GavaError):
+        m.forward_frames(vids, pre)            # grad enabled: the evaluation data path only

@@ -85,6 +85,18 @@ elif a.which == "patch":
     fn = lambda: hip.gemm(None, W, b, O, epilogue=hip.EPI_F32_PATCH, prec=prec, pos=pos, time=tim, n_patches=n, T=T,
                           M=BT * n, frames=x, frame_size=224, patch=16)
     fl = 2.0 * BT * n * D * Kp
+elif a.which == "patchu8":   # the patch embedding reading decoded uint8 videos (360 x 640, 32 frames each) itself
+    from gava_clip_amd.preprocess import ClipPreprocessor
+    n, Kp = 196, 768
+    pre = ClipPreprocessor(num_frames=T, sampling_rate=2, spatial_size=224)
+    vids = [torch.randint(0, 256, (32, 360, 640, 3), dtype=torch.uint8, device=d, generator=g) for _ in range(a.B)]
+    desc, keep = hip.clip_descriptors(vids, T=T, rate=2, size=224)
+    lut = pre.lut(d)
+    W, b, pos, tim = rn(D, Kp, scale=Kp ** -0.5), rn(D, dtype=torch.float32), rn(n + 1, D, dtype=torch.float32), rn(T, D, dtype=torch.float32)
+    O = torch.zeros(BT * (n + 1), D, device=d)
+    fn = lambda: hip.gemm(None, W, b, O, epilogue=hip.EPI_F32_PATCH, prec=prec, pos=pos, time=tim, n_patches=n, T=T,
+                          M=BT * n, frame_size=224, patch=16, clips=desc, clip_lut=lut)
+    fl = 2.0 * BT * n * D * Kp
 elif a.which == "attn":
     QKV, side, O = rn(R, 3 * D), rn(G + 2 * BT, 2 * D), torch.empty(R, D, dtype=dt, device=d)
     fn = lambda: hip.attention(QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, batch=BT, heads=H, n_q=n1, n_kmain=n1,
