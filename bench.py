@@ -138,10 +138,26 @@ def kernel_table(cfg, B, prec, fold=False):
     side = rn(G + 2 * BT, 2 * D)
     rows = []
 
+    pending = []
+
     def add(name, fn, flops, bytes_):
-        ms = event_time_ms(fn)
-        rows.append(dict(kernel=name, ms=round(ms, 4), tflops=round(flops / ms / 1e9, 1) if flops else None,
-                         gbps=round(bytes_ / ms / 1e6, 1), flops=flops, bytes=bytes_))
+        pending.append((name, fn, flops, bytes_))
+
+    def measure():
+        """Interleaved rounds in one process (every kernel sees the same thermal / clock history; a kernel timed alone
+        right after an idle gap or first in a list reads up to 10 % off): 10 warm-up launches each, then 3 rounds of 20
+        launches per kernel, median of the rounds."""
+        for _, fn, _, _ in pending:
+            for _ in range(10):
+                fn()
+        samples = [[] for _ in pending]
+        for _ in range(3):
+            for i, (_, fn, _, _) in enumerate(pending):
+                samples[i].append(event_time_ms(fn, iters=20, warmup=2))
+        for (name, fn, flops, bytes_), sm in zip(pending, samples):
+            ms = sorted(sm)[1]
+            rows.append(dict(kernel=name, ms=round(ms, 4), tflops=round(flops / ms / 1e9, 1) if flops else None,
+                             gbps=round(bytes_ / ms / 1e6, 1), flops=flops, bytes=bytes_))
 
     Rp = (R + 255) // 256 * 256
     rsum = torch.zeros(Rp, D // 64, 2, dtype=torch.float32, device=d)
@@ -187,6 +203,7 @@ def kernel_table(cfg, B, prec, fold=False):
     if fold:
         for k in ("qkv", "out", "fc1", "fc2"):   # the unfolded forms (training, GAVA_LN_FOLD=0), for comparison
             add(*second[k])
+    measure()
     return rows
 
 
@@ -361,7 +378,7 @@ def main():
                            "frac": round(fc1["flops"] / fc1_ms / 1e9 / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
                            "traffic_source": traffic_src,
                            "flops_per_launch": fc1["flops"], "ms_per_launch": round(fc1_ms, 4),
-                           "timed": "HIP events around 20 back-to-back launches after 10 warm-up launches",
+                           "timed": "HIP events around 20 back-to-back launches, median of 3 rounds interleaved with the other per-layer kernels, after 10 warm-up launches",
                            # the same kernel bracketed by an event pair per launch inside 5 forwards of the timed workload
                            # (includes ~10-20 us of event/dispatch latency per pair, which the back-to-back figure amortises)
                            "in_forward_ms_per_launch": round(in_fwd, 4) if in_fwd else None}

@@ -29,10 +29,13 @@ struct AttnParams {
   unsigned long long* dbg;
 };
 
-template <class P, int NKT, bool CAUSAL, bool PAIR = false>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
+// NWV waves per workgroup: 4, two workgroups per CU (LDS: 2 x 70 KiB at 224 keys); 8 for the 320-key class (ViT-L/14 with
+// T = 32: 100 KiB of K/V per workgroup, so only one fits a CU - eight waves keep two per SIMD).
+template <class P, int NKT, bool CAUSAL, bool PAIR = false, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void attention_kernel(const AttnParams p) {
   constexpr int KP = NKT * 16;
-  constexpr int NIT = (KP * 8 + 255) / 256;          // staging tasks (16 B of K and of V) per thread
+  constexpr int NTH = NWV * 64;
+  constexpr int NIT = (KP * 8 + NTH - 1) / NTH;      // staging tasks (16 B of K and of V) per thread
   __shared__ __attribute__((aligned(16))) char smem[2 * KP * LDS_ROW];
   char* Ks = smem;
   char* Vs = smem + KP * LDS_ROW;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     uint4 kv[NIT], vv[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int id = tid + it * 256;
+      const int id = tid + it * NTH;
       const int row = id >> 3, chunk = id & 7;
       const int rowc = row < p.n_keys ? row : 0;
       const int sidx = rowc - p.n_kmain;                               // >= 0: side row
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_loads = clock64(); }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int id = tid + it * 256;
+      const int id = tid + it * NTH;
       const int row = id >> 3, chunk = id & 7;
       if (id < KP * 8) {
         const bool ok = row < p.n_keys;
@@ -111,14 +114,14 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     // instead of one (the kernel is LDS- and VALU-bound, and the forward is power-capped: half the LDS traffic per
     // query).  Tiles 2*pr and 2*pr+1; pairs are dealt round-robin to the 4 waves.
     const int n_pairs = (n_qt + 1) >> 1;
-    for (int pr = wave; pr < n_pairs; pr += 4) {
+    for (int pr = wave; pr < n_pairs; pr += NWV) {
       const int qia = pr * 32 + fr, qib = qia + 16;
       s16x8_t na0 = q0, na1 = q1, nb0 = qb0, nb1 = qb1;
-      if (pr + 4 < n_pairs) {
-        const unsigned short* qp = q_ptr(2 * (pr + 4));
+      if (pr + NWV < n_pairs) {
+        const unsigned short* qp = q_ptr(2 * (pr + NWV));
         na0 = *reinterpret_cast<const s16x8_t*>(qp);
         na1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
-        const unsigned short* qq = q_ptr(2 * (pr + 4) + 1);
+        const unsigned short* qq = q_ptr(2 * (pr + NWV) + 1);
         nb0 = *reinterpret_cast<const s16x8_t*>(qq);
         nb1 = *reinterpret_cast<const s16x8_t*>(qq + 32);
       }
@@ -235,12 +238,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
       q0 = na0; q1 = na1; qb0 = nb0; qb1 = nb1;
     }
   } else
-  for (int qt = wave; qt < n_qt; qt += 4) {
+  for (int qt = wave; qt < n_qt; qt += NWV) {
     const int qi = qt * 16 + fr;
     // prefetch the next tile's Q while this one computes
     s16x8_t nq0 = q0, nq1 = q1;
-    if (qt + 4 < n_qt) {
-      const unsigned short* qp = q_ptr(qt + 4);
+    if (qt + NWV < n_qt) {
+      const unsigned short* qp = q_ptr(qt + NWV);
       nq0 = *reinterpret_cast<const s16x8_t*>(qp);
       nq1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
     }
@@ -354,27 +357,30 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
   }
   if (p.dbg && lane == 0 && blockIdx.x < 4096) {
     unsigned long long* d = p.dbg + (size_t)(blockIdx.x * 4 + wave) * 4;
-    d[0] = t_loads - t_start; d[1] = t_staged - t_loads; d[2] = clock64() - t_staged; d[3] = (n_qt - wave + 3) / 4;
+    d[0] = t_loads - t_start; d[1] = t_staged - t_loads; d[2] = clock64() - t_staged; d[3] = (n_qt - wave + NWV - 1) / NWV;
   }
 }
 
 template <class P>
 int launch_attn(const AttnParams& p, hipStream_t s) {
-  dim3 grid(p.batch * p.heads), block(256);
+  dim3 grid(p.batch * p.heads);
   const int tiles = (p.n_keys + 15) / 16;
   // two query tiles per wave for the big non-causal problems (vision blocks); GAVA_ATTN_PAIR=0 turns it off (A/B)
   static const bool pair_ok = !(getenv("GAVA_ATTN_PAIR") && getenv("GAVA_ATTN_PAIR")[0] == '0');
   const bool pair = pair_ok && !p.causal && !p.split && p.n_q >= 64;
-#define GAVA_ATTN(N)                                                                              \
+#define GAVA_ATTN(N, NWV)                                                                         \
   do {                                                                                            \
-    if (p.causal) hipLaunchKernelGGL((attention_kernel<P, N, true>), grid, block, 0, s, p);       \
-    else if (pair && N >= 14) hipLaunchKernelGGL((attention_kernel<P, (N >= 14 ? N : 14), false, true>), grid, block, 0, s, p); \
-    else hipLaunchKernelGGL((attention_kernel<P, N, false>), grid, block, 0, s, p);               \
+    dim3 blk(NWV * 64);                                                                           \
+    if (p.causal) hipLaunchKernelGGL((attention_kernel<P, N, true, false, NWV>), grid, blk, 0, s, p); \
+    else if (pair && N >= 14) hipLaunchKernelGGL((attention_kernel<P, (N >= 14 ? N : 14), false, true, NWV>), grid, blk, 0, s, p); \
+    else hipLaunchKernelGGL((attention_kernel<P, N, false, false, NWV>), grid, blk, 0, s, p);     \
   } while (0)
-  if (tiles <= 2) GAVA_ATTN(2);
-  else if (tiles <= 6) GAVA_ATTN(6);
-  else if (tiles <= 14) GAVA_ATTN(14);
-  else if (tiles <= 20) GAVA_ATTN(20);
+  // 8 waves for the 320-key class when there are enough query tiles to feed them (one workgroup per CU either way)
+  static const bool wide_ok = !(getenv("GAVA_ATTN_WIDE") && getenv("GAVA_ATTN_WIDE")[0] == '0');
+  if (tiles <= 2) GAVA_ATTN(2, 4);
+  else if (tiles <= 6) GAVA_ATTN(6, 4);
+  else if (tiles <= 14) GAVA_ATTN(14, 4);
+  else if (tiles <= 20) { if (wide_ok && p.n_q > 64) GAVA_ATTN(20, 8); else GAVA_ATTN(20, 4); }
   else return GAVA_EINVAL;
 #undef GAVA_ATTN
   GAVA_CHECK_LAUNCH();
