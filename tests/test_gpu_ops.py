@@ -403,3 +403,52 @@ def test_layernorm_folding_without_the_row_stats_launch(prec, M, D):
     with pytest.raises(hip.GavaError):
         hip.gemm(A[:, :128].contiguous(), rnd((128, 128), 0.1, 9).to(d).to(dt), None, torch.zeros(M, 128, dtype=dt, device=d),
                  epilogue=hip.EPI_H16, prec=prec, fold_partials=part, fold_s=fs[:128].contiguous(), fold_t=ft[:128].contiguous())
+
+
+@pytest.mark.parametrize("mode", ["partials", "stats"])
+def test_layernorm_fold_with_outlier_channels(mode):
+    """the folded LayerNorm takes its statistics from sum / sum-of-squares of the un-normalised stream and feeds the
+    GEMM a 16-bit copy of it.  Real CLIP activations carry a few channels with a large, constant offset; here three channels
+    sit at +60 / -45 / +25 on top of unit-variance data (row mean ~ 0.05, row variance ~ 8.6: E[x^2] - mean^2 keeps its
+    digits, but the fp16 copy of an outlier carries 0.03 of absolute rounding).  The folded GEMM must stay within the 16-bit
+    operand rounding of the unfolded LayerNorm + GEMM on the same inputs - measured and asserted, fp16 and bf16."""
+    d = dev()
+    M, D, N = 9000, 768, 1024
+    X = rnd((M, D), 1.0, 11).to(d)
+    X[:, 17] += 60.0
+    X[:, 300] -= 45.0
+    X[:, 555] += 25.0
+    gamma, beta = (1 + rnd((D,), 0.2, 5)).to(d), rnd((D,), 0.2, 6).to(d)
+    W = rnd((N, D), D ** -0.5, 7).to(d)
+    b = rnd((N,), 0.3, 8).to(d)
+    full = torch.nn.functional.layer_norm(X, (D,), gamma, beta) @ W.t() + b
+    for prec in PRECS:
+        dt = hip.h16_dtype(prec)
+        # a producer that reproduces X exactly: X = 0 * A W^T + resid
+        A = torch.zeros(M, 64, dtype=dt, device=d)
+        Wz = torch.zeros(D, 64, dtype=dt, device=d)
+        Xo = X.clone()
+        Mp = (M + 255) // 256 * 256
+        x16 = torch.zeros(Mp, D, dtype=dt, device=d)
+        Wf = (W * gamma).to(dt)
+        fs, ft = Wf.float().sum(1).contiguous(), (W @ beta + b).contiguous()
+        out = torch.zeros(M, N, dtype=dt, device=d)
+        if mode == "partials":
+            part = torch.zeros(Mp + 32, 4, 2, device=d)
+            hip.gemm(A, Wz, None, Xo, epilogue=hip.EPI_F32, prec=prec, resid=Xo, x16_out=x16, rowsum_out=part, rowsum_reduced=True)
+            hip.gemm(x16[:M], Wf, None, out, epilogue=hip.EPI_H16, prec=prec, fold_partials=part, fold_s=fs, fold_t=ft)
+        else:
+            rowsum = torch.zeros(Mp, D // 64, 2, device=d)
+            hip.gemm(A, Wz, None, Xo, epilogue=hip.EPI_F32, prec=prec, resid=Xo, x16_out=x16, rowsum_out=rowsum)
+            hip.gemm(x16[:M], Wf, None, out, epilogue=hip.EPI_H16, prec=prec, fold_stats=hip.row_stats(rowsum, D), fold_s=fs, fold_t=ft)
+        assert torch.equal(Xo, X)
+        # the unfolded path of the same precision: LayerNorm in fp32, its OUTPUT rounded to 16 bits, plain GEMM
+        xn16 = torch.zeros(M, D, dtype=dt, device=d)
+        hip.layernorm(X, gamma, beta, out16=xn16, prec=prec)
+        plain = torch.zeros(M, N, dtype=dt, device=d)
+        hip.gemm(xn16, W.to(dt), b, plain, epilogue=hip.EPI_H16, prec=prec)
+        scale = float(full.abs().max())
+        e_fold = float((out.float() - full).abs().max()) / scale
+        e_plain = float((plain.float() - full).abs().max()) / scale
+        print(f"\n[outliers/{mode}/prec {prec}] max error / max|ref|: folded {e_fold:.2e}, unfolded {e_plain:.2e}")
+        assert e_fold < 12 * EPS16[prec], (mode, prec, e_fold)
