@@ -1,8 +1,9 @@
 // attention.hip — fused softmax(Q K^T) V, head dim 64, 16-bit MFMA operands, fp32 softmax.
 //
 // gfx950 design: one workgroup (4 waves) per (problem, head).  The whole key set of a problem is
-// short (<= 320 keys: 214 for ViT-B/16 with T=8), so K and V of one head are staged ONCE in LDS
-// (160-byte padded rows: conflict-free for both the ds_read_b128 K-fragment reads and the
+// short (<= 320 keys: 214 for ViT-B/16 with T=8), so K and V of one head are staged ONCE in LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass; 128-byte rows whose 16-byte chunks are XOR-swizzled by
+// row & 6 on the source address - found by search to be conflict-free for both the ds_read_b128 K-fragment reads and the
 // ds_read_b64_tr_b16 transposed V reads) and softmax is single pass: no online rescaling.
 // Per 16-query tile a wave computes S^T = K Q^T with the KEY on the MFMA row, so every lane
 // holds, for its own query (lane&15), 4 consecutive keys per 16-key tile.  That accumulator
@@ -18,7 +19,31 @@
 
 namespace {
 
-constexpr int LDS_ROW = 160;  // bytes per K/V row in LDS (64 x 2 B + 32 B pad)
+constexpr int LDS_ROW = 128;  // bytes per K/V row in LDS (64 x 2 B, unpadded: 16-byte chunk c of row r sits at chunk c ^ (r & 6))
+
+// LDS reads by inline asm: after an LDS-DMA load the compiler guards every LDS read it can see with s_waitcnt vmcnt(0) (it
+// cannot tell which buffer a read touches, nor count past the DMA loads), which in the persistent kernel would wait for the
+// NEXT problem's K/V at the first K fragment of this one.  The asm reads are invisible to it; the lgkmcnt waits are ours
+// ("+v" ties a wait to the registers it covers, `pending` = LDS reads issued after them; LDS returns in order).
+__device__ __forceinline__ unsigned lds_addr(const char* ptr) { return (unsigned)(size_t)LDS_PTR(char, ptr); }
+__device__ __forceinline__ s16x8_t lds_b128(unsigned addr, int off) {
+  s16x8_t r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(off));
+  return r;
+}
+__device__ __forceinline__ s16x4_t lds_tr_b64(unsigned addr, int off) {
+  s16x4_t r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(off));
+  return r;
+}
+__device__ __forceinline__ void lgkm_wait(int pending, s16x8_t& a, s16x8_t& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(pending < 15 ? pending : 15));
+}
+__device__ __forceinline__ void lgkm_wait(int pending, s16x4_t (&a)[4], s16x4_t (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+               : "n"(pending < 15 ? pending : 15));
+}
 
 struct AttnParams {
   const unsigned short* q; const unsigned short* k; const unsigned short* v; long ld;
@@ -29,55 +54,22 @@ struct AttnParams {
   unsigned long long* dbg;
 };
 
-// NWV waves per workgroup: 4, two workgroups per CU (LDS: 2 x 70 KiB at 224 keys); 8 for the 320-key class (ViT-L/14 with
-// T = 32: 100 KiB of K/V per workgroup, so only one fits a CU - eight waves keep two per SIMD).
-template <class P, int NKT, bool CAUSAL, bool PAIR = false, int NWV = 4>
-__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void attention_kernel(const AttnParams p) {
-  constexpr int KP = NKT * 16;
-  constexpr int NTH = NWV * 64;
+constexpr float LOG2E = 1.4426950408889634f;
+#ifndef GAVA_ATTN_ONESUM   // row sums of P by one more MFMA per 32 keys (an all-ones "V" row) instead of one v_add per score
+#define GAVA_ATTN_ONESUM 1
+#endif
+
+// Stage K and V of problem (n, h) by LDS-DMA: lane l of a 1 KiB piece lands at row (l >> 3), physical chunk (l & 7), so it
+// fetches the logical chunk (l & 7) ^ (row & 6).  Rows beyond n_keys fetch row 0: their scores are masked to -inf, P = 0,
+// and 0 * V must stay finite.  No wait here: the caller owns the s_waitcnt vmcnt and the barrier.
+template <int KP, int NTH>
+__device__ __forceinline__ void stage_kv(const AttnParams& p, int n, int h, char* Ks, char* Vs, int tid, int wave) {
   constexpr int NIT = (KP * 8 + NTH - 1) / NTH;      // staging tasks (16 B of K and of V) per thread
-  __shared__ __attribute__((aligned(16))) char smem[2 * KP * LDS_ROW];
-  char* Ks = smem;
-  char* Vs = smem + KP * LDS_ROW;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = blockIdx.x / p.heads, h = blockIdx.x - n * p.heads;
-  const int fr = lane & 15, fg = lane >> 4;
-  const int n_qt = (p.n_q + 15) >> 4;
-  const unsigned long long t_start = p.dbg ? clock64() : 0;
-  unsigned long long t_loads = 0, t_staged = 0;
-
-  // ---- Q fragments of this wave's first query tile: in flight while K/V are staged
-  auto q_ptr = [&](int qt) {
-    const int qi = qt * 16 + fr;
-    const int qrow = qi < p.n_q ? qi : p.n_q - 1;
-    return p.q + ((long)n * p.qbr + qrow) * p.ldq + h * 64 + 8 * fg;
-  };
-  s16x8_t q0 = {0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0;
-  s16x8_t qb0 = q0, qb1 = q0;   // PAIR: second query tile of the wave's pair
-  if (PAIR) {
-    if (2 * wave < n_qt) {
-      const unsigned short* qp = q_ptr(2 * wave);
-      q0 = *reinterpret_cast<const s16x8_t*>(qp);
-      q1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
-      const unsigned short* qq = q_ptr(2 * wave + 1);   // row index clamped: a tile beyond n_q computes garbage, stores nothing
-      qb0 = *reinterpret_cast<const s16x8_t*>(qq);
-      qb1 = *reinterpret_cast<const s16x8_t*>(qq + 32);
-    }
-  } else if (wave < n_qt) {
-    const unsigned short* qp = q_ptr(wave);
-    q0 = *reinterpret_cast<const s16x8_t*>(qp);
-    q1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
-  }
-
-  // ---- stage K, V: branch-free address select, every load issued before the first LDS write.
-  // Rows beyond n_keys are zero so that 0 * V stays finite.
-  {
-    uint4 kv[NIT], vv[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int id = tid + it * NTH;
-      const int row = id >> 3, chunk = id & 7;
+  for (int it = 0; it < NIT; ++it) {
+    const int id = tid + it * NTH;
+    if (id < KP * 8) {                                                 // wave-uniform: KP * 8 is a multiple of 64
+      const int row = id >> 3, chunk = (id & 7) ^ (row & 6);
       const int rowc = row < p.n_keys ? row : 0;
       const int sidx = rowc - p.n_kmain;                               // >= 0: side row
       const long sr = sidx < p.n_g ? sidx
@@ -87,35 +79,226 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void attention_kernel(c
       const long off = (is_main ? ((long)n * p.n_kmain + rowc) * p.ld : sr * p.lds) + h * 64 + chunk * 8;
       const unsigned short* kb = is_main ? p.k : p.sk;
       const unsigned short* vb = is_main ? p.v : p.sv;
-      kv[it] = *reinterpret_cast<const uint4*>(kb + off);
-      vv[it] = *reinterpret_cast<const uint4*>(vb + off);
+      const int dst = (wave * 64 + it * NTH) * 16;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(kb + off), LDS_PTR(void, Ks + dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(vb + off), LDS_PTR(void, Vs + dst), 16, 0, 0);
     }
-    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_loads = clock64(); }
+  }
+}
+
+// Per-lane LDS addresses of the fragment reads (byte addresses; add the buffer base).
+struct FragAddr {
+  unsigned k0, k1;   // K fragments: row (tile * 16 + fr), logical chunks fg and fg + 4
+  unsigned v[4];     // transposed V reads: lane 4q+pp of a 16-lane group supplies row q, columns 4pp..4pp+3 of group dt
+};
+__device__ __forceinline__ FragAddr frag_addr(int fr, int fg) {
+  FragAddr a;
+  const int ksw = fr & 6;
+  a.k0 = fr * LDS_ROW + ((fg ^ ksw) << 4);
+  a.k1 = fr * LDS_ROW + (((fg + 4) ^ ksw) << 4);
+  // row 4 fg + (fr >> 2) (+16, + 32 per chunk: row & 6 unchanged), bytes (fr & 3) * 8 of the 32-byte group dt:
+  // logical chunk 2 dt + ((fr >> 1) & 1) -> physical chunk 2 (dt ^ gv) + ((fr >> 1) & 1), gv = (row & 6) >> 1
+  const int gv = ((4 * fg + (fr >> 2)) & 6) >> 1;
+  const int tr_off = (4 * fg + (fr >> 2)) * LDS_ROW + (fr & 3) * 8;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int id = tid + it * NTH;
-      const int row = id >> 3, chunk = id & 7;
-      if (id < KP * 8) {
-        const bool ok = row < p.n_keys;
-        *reinterpret_cast<uint4*>(Ks + row * LDS_ROW + chunk * 16) = ok ? kv[it] : make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(Vs + row * LDS_ROW + chunk * 16) = ok ? vv[it] : make_uint4(0, 0, 0, 0);
+  for (int dt = 0; dt < 4; ++dt) a.v[dt] = tr_off + ((dt ^ gv) << 5);
+  return a;
+}
+
+// Two query tiles (16 queries each) against all keys in LDS: every K fragment and every transposed V fragment read from
+// LDS feeds two MFMAs instead of one (half the LDS traffic per query).  Returns the unnormalised O^T accumulators and the
+// reciprocal row sums; the caller stores (pair_store) - the persistent kernel waits for its prefetch in between.
+template <class P, int NKT, int PCH = (NKT > 14 ? 2 : 4)>   // PCH: 32-key chunks of V in flight per batch (registers)
+__device__ __forceinline__ void pair_compute(const AttnParams& p, unsigned ks, unsigned vs, const FragAddr& fa, int fg,
+                                             s16x8_t q0, s16x8_t q1, s16x8_t qb0, s16x8_t qb1,
+                                             f32x4_t (&oa)[4], f32x4_t (&ob)[4], float& inva, float& invb) {
+  f32x4_t sa[NKT], sb[NKT];
+  constexpr int QCH = NKT % 7 == 0 ? 7 : (NKT % 5 == 0 ? 5 : (NKT % 4 == 0 ? 4 : (NKT % 3 == 0 ? 3 : 2)));
+  static_assert(NKT % QCH == 0, "key tiles per batch");
+  const unsigned ka0 = ks + fa.k0, ka1 = ks + fa.k1;
+  // S^T = K Q^T.  All K fragments of a batch are requested from LDS before the first MFMA.
+#pragma unroll
+  for (int c0 = 0; c0 < NKT; c0 += QCH) {
+    s16x8_t kf[QCH][2];
+#pragma unroll
+    for (int t = 0; t < QCH; ++t) {
+      kf[t][0] = lds_b128(ka0, (c0 + t) * 16 * LDS_ROW);
+      kf[t][1] = lds_b128(ka1, (c0 + t) * 16 * LDS_ROW);
+    }
+#pragma unroll
+    for (int t = 0; t < QCH; ++t) {
+      lgkm_wait(2 * (QCH - 1 - t), kf[t][0], kf[t][1]);
+      f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f}, b = a;
+      a = P::mfma(kf[t][0], q0, a);
+      b = P::mfma(kf[t][0], qb0, b);
+      a = P::mfma(kf[t][1], q1, a);
+      b = P::mfma(kf[t][1], qb1, b);
+      sa[c0 + t] = a;
+      sb[c0 + t] = b;
+    }
+  }
+  float mxa = -INFINITY, mxb = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    if (kt * 16 + 16 > p.n_keys) {
+      asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch: full tiles skip the masks
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = kt * 16 + 4 * fg + r < p.n_keys;
+        sa[kt][r] = ok ? sa[kt][r] : -INFINITY;
+        sb[kt][r] = ok ? sb[kt][r] : -INFINITY;
+      }
+    }
+    mxa = fmaxf(fmaxf(mxa, sa[kt][0]), fmaxf(sa[kt][1], fmaxf(sa[kt][2], sa[kt][3])));
+    mxb = fmaxf(fmaxf(mxb, sb[kt][0]), fmaxf(sb[kt][1], fmaxf(sb[kt][2], sb[kt][3])));
+  }
+  mxa = fmaxf(mxa, __shfl_xor(mxa, 16, 64)); mxb = fmaxf(mxb, __shfl_xor(mxb, 16, 64));
+  mxa = fmaxf(mxa, __shfl_xor(mxa, 32, 64)); mxb = fmaxf(mxb, __shfl_xor(mxb, 32, 64));
+  const float mna = -mxa * LOG2E, mnb = -mxb * LOG2E;
+  float suma = 0.f, sumb = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ea = __builtin_amdgcn_exp2f(fmaf(sa[kt][r], LOG2E, mna));
+      const float eb = __builtin_amdgcn_exp2f(fmaf(sb[kt][r], LOG2E, mnb));
+      sa[kt][r] = ea; sb[kt][r] = eb;
+      if (!GAVA_ATTN_ONESUM) { suma += ea; sumb += eb; }
+    }
+
+  // O^T = V^T P^T: every transposed V read of a batch is in flight before its MFMAs.
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { oa[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; ob[dt] = oa[dt]; }
+  // The softmax denominators ride on the matrix core: an all-ones A operand makes every row of the product the sum over
+  // all keys of the ROUNDED probabilities - the very numbers the numerator multiplies - with no cross-lane reduction.
+  f32x4_t osa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, osb = osa;
+  const unsigned short one = P::cvt(1.0f);
+  const s16x8_t ones = {(short)one, (short)one, (short)one, (short)one, (short)one, (short)one, (short)one, (short)one};
+  constexpr int NC2 = NKT / 2;                       // 32-key chunks
+  unsigned va[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) va[dt] = vs + fa.v[dt];
+#pragma unroll
+  for (int b0 = 0; b0 < NC2; b0 += PCH) {
+    const int nb = NC2 - b0 < PCH ? NC2 - b0 : PCH;  // compile-time after unrolling
+    s16x4_t t0[PCH][4], t1[PCH][4];
+#pragma unroll
+    for (int c = 0; c < PCH; ++c) {
+      if (c < nb) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          t0[c][dt] = lds_tr_b64(va[dt], (b0 + c) * 32 * LDS_ROW);
+          t1[c][dt] = lds_tr_b64(va[dt], (b0 + c) * 32 * LDS_ROW + 16 * LDS_ROW);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < PCH; ++c) {
+      if (c < nb) {
+        const int cc = b0 + c;
+        lgkm_wait(8 * (nb - 1 - c), t0[c], t1[c]);
+        const uint2 la = pack4<P>(sa[2 * cc][0], sa[2 * cc][1], sa[2 * cc][2], sa[2 * cc][3]);
+        const uint2 ha = pack4<P>(sa[2 * cc + 1][0], sa[2 * cc + 1][1], sa[2 * cc + 1][2], sa[2 * cc + 1][3]);
+        const uint2 lb = pack4<P>(sb[2 * cc][0], sb[2 * cc][1], sb[2 * cc][2], sb[2 * cc][3]);
+        const uint2 hb = pack4<P>(sb[2 * cc + 1][0], sb[2 * cc + 1][1], sb[2 * cc + 1][2], sb[2 * cc + 1][3]);
+        const s16x8_t pfa = __builtin_bit_cast(s16x8_t, make_uint4(la.x, la.y, ha.x, ha.y));
+        const s16x8_t pfb = __builtin_bit_cast(s16x8_t, make_uint4(lb.x, lb.y, hb.x, hb.y));
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const s16x8_t vf = __builtin_shufflevector(t0[c][dt], t1[c][dt], 0, 1, 2, 3, 4, 5, 6, 7);
+          oa[dt] = P::mfma(vf, pfa, oa[dt]);
+          ob[dt] = P::mfma(vf, pfb, ob[dt]);
+        }
+        if (GAVA_ATTN_ONESUM) {
+          osa = P::mfma(ones, pfa, osa);
+          osb = P::mfma(ones, pfb, osb);
+        }
       }
     }
   }
-  __syncthreads();
+  if (GAVA_ATTN_ONESUM) {
+    suma = osa[0]; sumb = osb[0];
+  } else {
+    suma = sum_across_lane_groups(suma);
+    sumb = sum_across_lane_groups(sumb);
+  }
+  inva = __builtin_amdgcn_rcpf(suma); invb = __builtin_amdgcn_rcpf(sumb);
+}
+
+// O^T leaves each lane with 4 consecutive head-dim columns of its own query: 8-byte stores.
+template <class P>
+__device__ __forceinline__ void pair_store(const AttnParams& p, int n, int h, int pr, int fr, int fg,
+                                           const f32x4_t (&oa)[4], const f32x4_t (&ob)[4], float inva, float invb) {
+  const int qia = pr * 32 + fr, qib = qia + 16;
+  if (qia < p.n_q) {
+    unsigned short* op = p.out + ((long)n * p.n_q + qia) * p.ldo + h * 64 + 4 * fg;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<uint2*>(op + dt * 16) = pack4<P>(oa[dt][0] * inva, oa[dt][1] * inva, oa[dt][2] * inva, oa[dt][3] * inva);
+  }
+  if (qib < p.n_q) {
+    unsigned short* op = p.out + ((long)n * p.n_q + qib) * p.ldo + h * 64 + 4 * fg;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<uint2*>(op + dt * 16) = pack4<P>(ob[dt][0] * invb, ob[dt][1] * invb, ob[dt][2] * invb, ob[dt][3] * invb);
+  }
+}
+
+__device__ __forceinline__ const unsigned short* q_row_ptr(const AttnParams& p, int n, int h, int qt, int fr, int fg) {
+  const int qi = qt * 16 + fr;
+  const int qrow = qi < p.n_q ? qi : p.n_q - 1;   // clamped: a tile beyond n_q computes garbage, stores nothing
+  return p.q + ((long)n * p.qbr + qrow) * p.ldq + h * 64 + 8 * fg;
+}
+
+// One workgroup (4 waves) per (problem, head), two workgroups per CU: 2 x 56 KiB of LDS at 224 keys, 2 x 80 KiB (all of
+// it) for the 320-key class (ViT-L/14 with T = 32).
+template <class P, int NKT, bool CAUSAL, bool PAIR = false>
+__global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
+  constexpr int NWV = 4;
+  constexpr int KP = NKT * 16;
+  __shared__ __attribute__((aligned(16))) char Ks[KP * LDS_ROW];
+  __shared__ __attribute__((aligned(16))) char Vs[KP * LDS_ROW];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.x / p.heads, h = blockIdx.x - n * p.heads;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n_qt = (p.n_q + 15) >> 4;
+  const unsigned long long t_start = p.dbg ? clock64() : 0;
+  unsigned long long t_loads = 0, t_staged = 0;
+
+  // ---- Q fragments of this wave's first query tile(s): in flight while K/V are staged
+  auto q_ptr = [&](int qt) { return q_row_ptr(p, n, h, qt, fr, fg); };
+  s16x8_t q0 = {0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0;
+  s16x8_t qb0 = q0, qb1 = q0;   // PAIR: second query tile of the wave's pair
+  if constexpr (PAIR) {
+    if (2 * wave < n_qt) {
+      const unsigned short* qp = q_ptr(2 * wave);
+      q0 = *reinterpret_cast<const s16x8_t*>(qp);
+      q1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
+      const unsigned short* qq = q_ptr(2 * wave + 1);
+      qb0 = *reinterpret_cast<const s16x8_t*>(qq);
+      qb1 = *reinterpret_cast<const s16x8_t*>(qq + 32);
+    }
+  } else if (wave < n_qt) {
+    const unsigned short* qp = q_ptr(wave);
+    q0 = *reinterpret_cast<const s16x8_t*>(qp);
+    q1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
+  }
+
+  stage_kv<KP, NWV * 64>(p, n, h, Ks, Vs, tid, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (p.dbg) t_loads = clock64();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   if (p.dbg) t_staged = clock64();
 
-  // transposed-read lane address: lane 4q+pp of a 16-lane group supplies row q, columns 4pp..4pp+3
-  const int tr_off = (4 * fg + (fr >> 2)) * LDS_ROW + (fr & 3) * 8;
-  constexpr float LOG2E = 1.4426950408889634f;
+  const FragAddr fa = frag_addr(fr, fg);
+  const unsigned ks = lds_addr(Ks), vs = lds_addr(Vs);
 
   if constexpr (PAIR) {
-    // Two query tiles per wave and pass: every K fragment and every transposed V fragment read from LDS feeds two MFMAs
-    // instead of one (the kernel is LDS- and VALU-bound, and the forward is power-capped: half the LDS traffic per
-    // query).  Tiles 2*pr and 2*pr+1; pairs are dealt round-robin to the 4 waves.
+    // Tiles 2*pr and 2*pr+1; pairs are dealt round-robin to the 4 waves.
     const int n_pairs = (n_qt + 1) >> 1;
     for (int pr = wave; pr < n_pairs; pr += NWV) {
-      const int qia = pr * 32 + fr, qib = qia + 16;
       s16x8_t na0 = q0, na1 = q1, nb0 = qb0, nb1 = qb1;
       if (pr + NWV < n_pairs) {
         const unsigned short* qp = q_ptr(2 * (pr + NWV));
@@ -125,116 +308,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void attention_kernel(c
         nb0 = *reinterpret_cast<const s16x8_t*>(qq);
         nb1 = *reinterpret_cast<const s16x8_t*>(qq + 32);
       }
-      f32x4_t sa[NKT], sb[NKT];
-      constexpr int QCH = NKT % 7 == 0 ? 7 : (NKT % 5 == 0 ? 5 : (NKT % 4 == 0 ? 4 : (NKT % 3 == 0 ? 3 : 2)));
-      static_assert(NKT % QCH == 0, "key tiles per batch");
-#pragma unroll
-      for (int c0 = 0; c0 < NKT; c0 += QCH) {
-        s16x8_t kf[QCH][2];
-#pragma unroll
-        for (int t = 0; t < QCH; ++t) {
-          const char* kr = Ks + ((c0 + t) * 16 + fr) * LDS_ROW + fg * 16;
-          kf[t][0] = *reinterpret_cast<const s16x8_t*>(kr);
-          kf[t][1] = *reinterpret_cast<const s16x8_t*>(kr + 64);
-        }
-#pragma unroll
-        for (int t = 0; t < QCH; ++t) {
-          f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f}, b = a;
-          a = P::mfma(kf[t][0], q0, a);
-          b = P::mfma(kf[t][0], qb0, b);
-          a = P::mfma(kf[t][1], q1, a);
-          b = P::mfma(kf[t][1], qb1, b);
-          sa[c0 + t] = a;
-          sb[c0 + t] = b;
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * QCH, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * QCH, 0);
-      }
-      float mxa = -INFINITY, mxb = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) {
-        if (kt * 16 + 16 > p.n_keys) {
-          asm volatile("" ::: "memory");
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool ok = kt * 16 + 4 * fg + r < p.n_keys;
-            sa[kt][r] = ok ? sa[kt][r] : -INFINITY;
-            sb[kt][r] = ok ? sb[kt][r] : -INFINITY;
-          }
-        }
-        mxa = fmaxf(fmaxf(mxa, sa[kt][0]), fmaxf(sa[kt][1], fmaxf(sa[kt][2], sa[kt][3])));
-        mxb = fmaxf(fmaxf(mxb, sb[kt][0]), fmaxf(sb[kt][1], fmaxf(sb[kt][2], sb[kt][3])));
-      }
-      mxa = fmaxf(mxa, __shfl_xor(mxa, 16, 64)); mxb = fmaxf(mxb, __shfl_xor(mxb, 16, 64));
-      mxa = fmaxf(mxa, __shfl_xor(mxa, 32, 64)); mxb = fmaxf(mxb, __shfl_xor(mxb, 32, 64));
-      const float mna = -mxa * LOG2E, mnb = -mxb * LOG2E;
-      float suma = 0.f, sumb = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float ea = __builtin_amdgcn_exp2f(fmaf(sa[kt][r], LOG2E, mna));
-          const float eb = __builtin_amdgcn_exp2f(fmaf(sb[kt][r], LOG2E, mnb));
-          sa[kt][r] = ea; suma += ea;
-          sb[kt][r] = eb; sumb += eb;
-        }
-      suma = sum_across_lane_groups(suma);
-      sumb = sum_across_lane_groups(sumb);
-      const float inva = __builtin_amdgcn_rcpf(suma), invb = __builtin_amdgcn_rcpf(sumb);
-
       f32x4_t oa[4], ob[4];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) { oa[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; ob[dt] = oa[dt]; }
-      constexpr int NC2 = NKT / 2;                       // 32-key chunks
-      constexpr int PCH = 4;                             // chunks per batch (the last batch may be shorter)
-#pragma unroll
-      for (int b0 = 0; b0 < NC2; b0 += PCH) {
-        constexpr int dummy = 0; (void)dummy;
-        const int nb = NC2 - b0 < PCH ? NC2 - b0 : PCH;  // compile-time after unrolling
-        s16x4_t t0[PCH][4], t1[PCH][4];
-#pragma unroll
-        for (int c = 0; c < PCH; ++c) {
-          if (c < nb) {
-            const char* vb = Vs + (b0 + c) * 32 * LDS_ROW + tr_off;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-              t0[c][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + dt * 32));
-              t1[c][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + 16 * LDS_ROW + dt * 32));
-            }
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < PCH; ++c) {
-          if (c < nb) {
-            const int cc = b0 + c;
-            const uint2 la = pack4<P>(sa[2 * cc][0], sa[2 * cc][1], sa[2 * cc][2], sa[2 * cc][3]);
-            const uint2 ha = pack4<P>(sa[2 * cc + 1][0], sa[2 * cc + 1][1], sa[2 * cc + 1][2], sa[2 * cc + 1][3]);
-            const uint2 lb = pack4<P>(sb[2 * cc][0], sb[2 * cc][1], sb[2 * cc][2], sb[2 * cc][3]);
-            const uint2 hb = pack4<P>(sb[2 * cc + 1][0], sb[2 * cc + 1][1], sb[2 * cc + 1][2], sb[2 * cc + 1][3]);
-            const s16x8_t pfa = __builtin_bit_cast(s16x8_t, make_uint4(la.x, la.y, ha.x, ha.y));
-            const s16x8_t pfb = __builtin_bit_cast(s16x8_t, make_uint4(lb.x, lb.y, hb.x, hb.y));
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-              const s16x8_t vf = __builtin_shufflevector(t0[c][dt], t1[c][dt], 0, 1, 2, 3, 4, 5, 6, 7);
-              oa[dt] = P::mfma(vf, pfa, oa[dt]);
-              ob[dt] = P::mfma(vf, pfb, ob[dt]);
-            }
-          }
-        }
-      }
-      const int Dm = p.heads * 64; (void)Dm;
-      if (qia < p.n_q) {
-        unsigned short* op = p.out + ((long)n * p.n_q + qia) * p.ldo + h * 64 + 4 * fg;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-          *reinterpret_cast<uint2*>(op + dt * 16) = pack4<P>(oa[dt][0] * inva, oa[dt][1] * inva, oa[dt][2] * inva, oa[dt][3] * inva);
-      }
-      if (qib < p.n_q) {
-        unsigned short* op = p.out + ((long)n * p.n_q + qib) * p.ldo + h * 64 + 4 * fg;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-          *reinterpret_cast<uint2*>(op + dt * 16) = pack4<P>(ob[dt][0] * invb, ob[dt][1] * invb, ob[dt][2] * invb, ob[dt][3] * invb);
-      }
+      float inva, invb;
+      pair_compute<P, NKT>(p, ks, vs, fa, fg, q0, q1, qb0, qb1, oa, ob, inva, invb);
+      pair_store<P>(p, n, h, pr, fr, fg, oa, ob, inva, invb);
       q0 = na0; q1 = na1; qb0 = nb0; qb1 = nb1;
     }
   } else
@@ -252,24 +329,23 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void attention_kernel(c
     // compiler otherwise emits read -> wait -> 2 MFMA per tile and exposes the LDS latency 14 times).
     f32x4_t s[NKT];
     constexpr int QCH = NKT <= 14 ? NKT : NKT / 2;
+    const unsigned ka0 = ks + fa.k0, ka1 = ks + fa.k1;
 #pragma unroll
     for (int c0 = 0; c0 < NKT; c0 += QCH) {
       s16x8_t kf[QCH][2];
 #pragma unroll
       for (int t = 0; t < QCH; ++t) {
-        const char* kr = Ks + ((c0 + t) * 16 + fr) * LDS_ROW + fg * 16;
-        kf[t][0] = *reinterpret_cast<const s16x8_t*>(kr);
-        kf[t][1] = *reinterpret_cast<const s16x8_t*>(kr + 64);
+        kf[t][0] = lds_b128(ka0, (c0 + t) * 16 * LDS_ROW);
+        kf[t][1] = lds_b128(ka1, (c0 + t) * 16 * LDS_ROW);
       }
 #pragma unroll
       for (int t = 0; t < QCH; ++t) {
+        lgkm_wait(2 * (QCH - 1 - t), kf[t][0], kf[t][1]);
         f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         a = P::mfma(kf[t][0], q0, a);
         a = P::mfma(kf[t][1], q1, a);
         s[c0 + t] = a;
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * QCH, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * QCH, 0);
     }
     // mask only the key tiles that can hold invalid keys (wave-uniform test), then row max
     float mx = -INFINITY;
@@ -309,21 +385,24 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void attention_kernel(c
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     constexpr int NC2 = NKT / 2;                       // 32-key chunks
     constexpr int PCH = NC2 <= 7 ? NC2 : NC2 / 2;      // chunks per batch
+    unsigned va[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) va[dt] = vs + fa.v[dt];
 #pragma unroll
     for (int b0 = 0; b0 < NC2; b0 += PCH) {
       s16x4_t t0[PCH][4], t1[PCH][4];
 #pragma unroll
       for (int c = 0; c < PCH; ++c) {
-        const char* vb = Vs + (b0 + c) * 32 * LDS_ROW + tr_off;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          t0[c][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + dt * 32));
-          t1[c][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + 16 * LDS_ROW + dt * 32));
+          t0[c][dt] = lds_tr_b64(va[dt], (b0 + c) * 32 * LDS_ROW);
+          t1[c][dt] = lds_tr_b64(va[dt], (b0 + c) * 32 * LDS_ROW + 16 * LDS_ROW);
         }
       }
 #pragma unroll
       for (int c = 0; c < PCH; ++c) {
         const int cc = b0 + c;
+        lgkm_wait(8 * (PCH - 1 - c), t0[c], t1[c]);
         const uint2 lo = pack4<P>(s[2 * cc][0], s[2 * cc][1], s[2 * cc][2], s[2 * cc][3]);
         const uint2 hi = pack4<P>(s[2 * cc + 1][0], s[2 * cc + 1][1], s[2 * cc + 1][2], s[2 * cc + 1][3]);
         const s16x8_t pf = __builtin_bit_cast(s16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
@@ -333,8 +412,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void attention_kernel(c
           o[dt] = P::mfma(vf, pf, o[dt]);
         }
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, 8 * PCH, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * PCH, 0);
     }
     if (qi < p.n_q) {
       unsigned short* op = p.out + ((long)n * p.n_q + qi) * p.ldo + h * 64 + 4 * fg;
@@ -361,26 +438,116 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void attention_kernel(c
   }
 }
 
+#ifndef GAVA_PERSIST_PCH
+#define GAVA_PERSIST_PCH 2
+#endif
+// Persistent form for the vision blocks: one workgroup of 8 waves per CU walks the (frame, head) problems with a stride of
+// the grid, K/V double-buffered in LDS (2 x 2 x KP rows): the LDS-DMA loads and the Q fragments of the NEXT problem are
+// issued before the current one is computed, so the load phase (a quarter of a workgroup's life in the kernel above, and
+// only partly covered by the second workgroup of the CU) disappears behind the MFMA/softmax work.  One query-tile pair
+// per wave (n_q <= 256).  One barrier per problem: a wave arrives after its own share of the next problem's loads has
+// landed (vmcnt(0) BEFORE its output stores, which then drain under the next problem) and after its last LDS read of the
+// current buffer, which is all the next iteration needs.
+template <class P, int NKT>
+__global__ __launch_bounds__(512, 1) void attention_persist_kernel(const AttnParams p, const int n_prob) {
+  constexpr int NWV = 8;
+  constexpr int KP = NKT * 16;
+  constexpr int BUF = KP * LDS_ROW;
+  __shared__ __attribute__((aligned(16))) char Ks[2 * BUF];
+  __shared__ __attribute__((aligned(16))) char Vs[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n_qt = (p.n_q + 15) >> 4;
+  const bool has_pair = 2 * wave < n_qt;
+  const FragAddr fa = frag_addr(fr, fg);
+  const unsigned ks = lds_addr(Ks), vs = lds_addr(Vs);
+
+  int prob = blockIdx.x;
+  if (prob >= n_prob) return;
+  int n = prob / p.heads, h = prob - n * p.heads;
+  s16x8_t q0 = {0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, qb0 = q0, qb1 = q0;
+  stage_kv<KP, NWV * 64>(p, n, h, Ks, Vs, tid, wave);
+  if (has_pair) {
+    const unsigned short* qp = q_row_ptr(p, n, h, 2 * wave, fr, fg);
+    q0 = *reinterpret_cast<const s16x8_t*>(qp);
+    q1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
+    const unsigned short* qq = q_row_ptr(p, n, h, 2 * wave + 1, fr, fg);
+    qb0 = *reinterpret_cast<const s16x8_t*>(qq);
+    qb1 = *reinterpret_cast<const s16x8_t*>(qq + 32);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(qb0), "+v"(qb1) : : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  int buf = 0;
+  for (;;) {
+    const int nxt = prob + gridDim.x;
+    const bool more = nxt < n_prob;                     // workgroup-uniform
+    const int nn = nxt / p.heads, nh = nxt - nn * p.heads;
+    s16x8_t na0 = q0, na1 = q1, nb0 = qb0, nb1 = qb1;
+    if (more) {
+      stage_kv<KP, NWV * 64>(p, nn, nh, Ks + (buf ^ 1) * BUF, Vs + (buf ^ 1) * BUF, tid, wave);
+      if (has_pair) {
+        const unsigned short* qp = q_row_ptr(p, nn, nh, 2 * wave, fr, fg);
+        na0 = *reinterpret_cast<const s16x8_t*>(qp);
+        na1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
+        const unsigned short* qq = q_row_ptr(p, nn, nh, 2 * wave + 1, fr, fg);
+        nb0 = *reinterpret_cast<const s16x8_t*>(qq);
+        nb1 = *reinterpret_cast<const s16x8_t*>(qq + 32);
+      }
+    }
+    if (has_pair) {
+      f32x4_t oa[4], ob[4];
+      float inva, invb;
+      pair_compute<P, NKT, GAVA_PERSIST_PCH>(p, ks + buf * BUF, vs + buf * BUF, fa, fg, q0, q1, qb0, qb1, oa, ob, inva, invb);
+      // the next problem's K/V pieces and Q fragments of this wave have landed; nothing of this problem is stored yet
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(na0), "+v"(na1), "+v"(nb0), "+v"(nb1) : : "memory");
+      pair_store<P>(p, n, h, wave, fr, fg, oa, ob, inva, invb);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (!more) break;
+    q0 = na0; q1 = na1; qb0 = nb0; qb1 = nb1;
+    prob = nxt; n = nn; h = nh; buf ^= 1;
+  }
+}
+
 template <class P>
 int launch_attn(const AttnParams& p, hipStream_t s) {
-  dim3 grid(p.batch * p.heads);
+  const int n_prob = p.batch * p.heads;
+  dim3 grid(n_prob), blk(256);
   const int tiles = (p.n_keys + 15) / 16;
   // two query tiles per wave for the big non-causal problems (vision blocks); GAVA_ATTN_PAIR=0 turns it off (A/B)
   static const bool pair_ok = !(getenv("GAVA_ATTN_PAIR") && getenv("GAVA_ATTN_PAIR")[0] == '0');
   const bool pair = pair_ok && !p.causal && !p.split && p.n_q >= 64;
-#define GAVA_ATTN(N, NWV)                                                                         \
+  // persistent double-buffered form: the 224-key class with at most 8 query-tile pairs, enough problems to keep every CU
+  // busy for several rounds; GAVA_ATTN_PERSIST=0 turns it off (A/B)
+  static const bool persist_ok = !(getenv("GAVA_ATTN_PERSIST") && getenv("GAVA_ATTN_PERSIST")[0] == '0');
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GAVA_ELAUNCH;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 8;
+  }
+  if (persist_ok && pair && tiles > 6 && tiles <= 14 && p.n_q <= 256 && !p.dbg && n_prob >= 4 * n_cu) {
+    hipLaunchKernelGGL((attention_persist_kernel<P, 14>), dim3(n_cu), dim3(512), 0, s, p, n_prob);
+    GAVA_CHECK_LAUNCH();
+    return GAVA_OK;
+  }
+#define GAVA_ATTN(N)                                                                              \
   do {                                                                                            \
-    dim3 blk(NWV * 64);                                                                           \
-    if (p.causal) hipLaunchKernelGGL((attention_kernel<P, N, true, false, NWV>), grid, blk, 0, s, p); \
-    else if (pair && N >= 14) hipLaunchKernelGGL((attention_kernel<P, (N >= 14 ? N : 14), false, true, NWV>), grid, blk, 0, s, p); \
-    else hipLaunchKernelGGL((attention_kernel<P, N, false, false, NWV>), grid, blk, 0, s, p);     \
+    if (p.causal) hipLaunchKernelGGL((attention_kernel<P, N, true, false>), grid, blk, 0, s, p);  \
+    else if (pair && N >= 14) hipLaunchKernelGGL((attention_kernel<P, (N >= 14 ? N : 14), false, true>), grid, blk, 0, s, p); \
+    else hipLaunchKernelGGL((attention_kernel<P, N, false, false>), grid, blk, 0, s, p);          \
   } while (0)
-  // 8 waves for the 320-key class when there are enough query tiles to feed them (one workgroup per CU either way)
-  static const bool wide_ok = !(getenv("GAVA_ATTN_WIDE") && getenv("GAVA_ATTN_WIDE")[0] == '0');
-  if (tiles <= 2) GAVA_ATTN(2, 4);
-  else if (tiles <= 6) GAVA_ATTN(6, 4);
-  else if (tiles <= 14) GAVA_ATTN(14, 4);
-  else if (tiles <= 20) { if (wide_ok && p.n_q > 64) GAVA_ATTN(20, 8); else GAVA_ATTN(20, 4); }
+  if (tiles <= 2) GAVA_ATTN(2);
+  else if (tiles <= 6) GAVA_ATTN(6);
+  else if (tiles <= 14) GAVA_ATTN(14);
+  else if (tiles <= 20) GAVA_ATTN(20);
   else return GAVA_EINVAL;
 #undef GAVA_ATTN
   GAVA_CHECK_LAUNCH();

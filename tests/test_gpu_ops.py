@@ -153,9 +153,12 @@ def test_attention_plain_and_causal(prec, batch, heads, L, causal):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("B,T,G,n_main,heads", [(2, 4, 4, 17, 2), (2, 8, 8, 197, 12), (1, 16, 8, 197, 3)])
+@pytest.mark.parametrize("B,T,G,n_main,heads", [(2, 4, 4, 17, 2), (2, 8, 8, 197, 12), (1, 16, 8, 197, 3),
+                                                (11, 8, 8, 197, 13), (32, 8, 4, 130, 6)])
 def test_attention_with_side_rows(prec, B, T, G, n_main, heads):
-    """Vision layout: per-frame main tokens + [G global | T per-clip local | 1 per-frame summary]."""
+    """Vision layout: per-frame main tokens + [G global | T per-clip local | 1 per-frame summary].  The last two cases have
+    enough (frame, head) problems (>= 4 per CU) for the persistent double-buffered kernel, with an uneven number of
+    problems per workgroup."""
     d = dev()
     dt = hip.h16_dtype(prec)
     D, BT = heads * 64, B * T

@@ -8,14 +8,16 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch
 from gava_clip_amd import hip
-from gava_clip_amd.config import VIT_B16_T8 as cfg
+from gava_clip_amd import config as _config
 
 ap = argparse.ArgumentParser()
 ap.add_argument("which")
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--B", type=int, default=64)
 ap.add_argument("--prec", default="fp16")
+ap.add_argument("--cfg", default="VIT_B16_T8", help="config name in gava_clip_amd.config (VIT_L14_T32 for the 320-key attention class)")
 a = ap.parse_args()
+cfg = getattr(_config, a.cfg)
 prec = hip.PREC_NAMES[a.prec]
 dt = hip.h16_dtype(prec)
 d = torch.device("cuda")
