@@ -21,28 +21,15 @@ namespace {
 
 constexpr int LDS_ROW = 128;  // bytes per K/V row in LDS (64 x 2 B, unpadded: 16-byte chunk c of row r sits at chunk c ^ (r & 6))
 
-// LDS reads by inline asm: after an LDS-DMA load the compiler guards every LDS read it can see with s_waitcnt vmcnt(0) (it
-// cannot tell which buffer a read touches, nor count past the DMA loads), which in the persistent kernel would wait for the
-// NEXT problem's K/V at the first K fragment of this one.  The asm reads are invisible to it; the lgkmcnt waits are ours
-// ("+v" ties a wait to the registers it covers, `pending` = LDS reads issued after them; LDS returns in order).
+// LDS-DMA by inline asm.  Through the builtin the compiler knows that a VMEM load writes LDS and guards every later LDS read
+// with s_waitcnt vmcnt(0) (it cannot tell buffers apart, nor count past the DMA loads): in the persistent kernel that
+// would wait for the NEXT problem's K/V at the first K fragment of this one.  Issued from asm the transfer is invisible
+// to it; every consumer below sits behind an explicit s_waitcnt vmcnt + s_barrier.  (The compiler's own vmcnt waits for
+// the loads it does track stay correct: they can only over-wait, VMEM returns in order.)  M0 = LDS base of the 1 KiB
+// piece; nothing else in these kernels uses M0.
 __device__ __forceinline__ unsigned lds_addr(const char* ptr) { return (unsigned)(size_t)LDS_PTR(char, ptr); }
-__device__ __forceinline__ s16x8_t lds_b128(unsigned addr, int off) {
-  s16x8_t r;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(off));
-  return r;
-}
-__device__ __forceinline__ s16x4_t lds_tr_b64(unsigned addr, int off) {
-  s16x4_t r;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(off));
-  return r;
-}
-__device__ __forceinline__ void lgkm_wait(int pending, s16x8_t& a, s16x8_t& b) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(pending < 15 ? pending : 15));
-}
-__device__ __forceinline__ void lgkm_wait(int pending, s16x4_t (&a)[4], s16x4_t (&b)[4]) {
-  asm volatile("s_waitcnt lgkmcnt(%8)"
-               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
-               : "n"(pending < 15 ? pending : 15));
+__device__ __forceinline__ void dma16(const unsigned short* src, unsigned lds_piece) {
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_piece), "v"(src) : "memory");
 }
 
 struct AttnParams {
@@ -80,8 +67,8 @@ __device__ __forceinline__ void stage_kv(const AttnParams& p, int n, int h, char
       const unsigned short* kb = is_main ? p.k : p.sk;
       const unsigned short* vb = is_main ? p.v : p.sv;
       const int dst = (wave * 64 + it * NTH) * 16;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(kb + off), LDS_PTR(void, Ks + dst), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(vb + off), LDS_PTR(void, Vs + dst), 16, 0, 0);
+      dma16(kb + off, lds_addr(Ks) + dst);
+      dma16(vb + off, lds_addr(Vs) + dst);
     }
   }
 }
@@ -108,26 +95,35 @@ __device__ __forceinline__ FragAddr frag_addr(int fr, int fg) {
 // Two query tiles (16 queries each) against all keys in LDS: every K fragment and every transposed V fragment read from
 // LDS feeds two MFMAs instead of one (half the LDS traffic per query).  Returns the unnormalised O^T accumulators and the
 // reciprocal row sums; the caller stores (pair_store) - the persistent kernel waits for its prefetch in between.
-template <class P, int NKT, int PCH = (NKT > 14 ? 2 : 4)>   // PCH: 32-key chunks of V in flight per batch (registers)
-__device__ __forceinline__ void pair_compute(const AttnParams& p, unsigned ks, unsigned vs, const FragAddr& fa, int fg,
+// FULL: leading key tiles the dispatcher guarantees to hold only valid keys (no mask code for them at all); PCH: 32-key
+// chunks of V in flight per batch (registers).
+template <class P, int NKT, int FULL, int PCH = (NKT > 14 ? 2 : 4)>
+__device__ __forceinline__ void pair_compute(const AttnParams& p, const char* ks, const char* vs, const FragAddr& fa, int fg,
                                              s16x8_t q0, s16x8_t q1, s16x8_t qb0, s16x8_t qb1,
-                                             f32x4_t (&oa)[4], f32x4_t (&ob)[4], float& inva, float& invb) {
+                                             f32x4_t (&oa)[4], f32x4_t (&ob)[4], float& inva, float& invb,
+                                             unsigned long long* stamps = nullptr) {
+#ifdef GAVA_ATTN_STAMPS   // diagnostics build only (tools/attn_stamps.py): phase boundaries of the first pair of a wave
+#define ATTN_STAMP(i, dep) do { if (stamps) { asm volatile("" :: "v"(dep)); stamps[i] = clock64(); } } while (0)
+#else
+#define ATTN_STAMP(i, dep) do { } while (0)
+#endif
+  ATTN_STAMP(0, q0);
   f32x4_t sa[NKT], sb[NKT];
   constexpr int QCH = NKT % 7 == 0 ? 7 : (NKT % 5 == 0 ? 5 : (NKT % 4 == 0 ? 4 : (NKT % 3 == 0 ? 3 : 2)));
   static_assert(NKT % QCH == 0, "key tiles per batch");
-  const unsigned ka0 = ks + fa.k0, ka1 = ks + fa.k1;
+  const char* ka0 = ks + fa.k0;
+  const char* ka1 = ks + fa.k1;
   // S^T = K Q^T.  All K fragments of a batch are requested from LDS before the first MFMA.
 #pragma unroll
   for (int c0 = 0; c0 < NKT; c0 += QCH) {
     s16x8_t kf[QCH][2];
 #pragma unroll
     for (int t = 0; t < QCH; ++t) {
-      kf[t][0] = lds_b128(ka0, (c0 + t) * 16 * LDS_ROW);
-      kf[t][1] = lds_b128(ka1, (c0 + t) * 16 * LDS_ROW);
+      kf[t][0] = *reinterpret_cast<const s16x8_t*>(ka0 + (c0 + t) * 16 * LDS_ROW);
+      kf[t][1] = *reinterpret_cast<const s16x8_t*>(ka1 + (c0 + t) * 16 * LDS_ROW);
     }
 #pragma unroll
     for (int t = 0; t < QCH; ++t) {
-      lgkm_wait(2 * (QCH - 1 - t), kf[t][0], kf[t][1]);
       f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f}, b = a;
       a = P::mfma(kf[t][0], q0, a);
       b = P::mfma(kf[t][0], qb0, b);
@@ -136,15 +132,21 @@ __device__ __forceinline__ void pair_compute(const AttnParams& p, unsigned ks, u
       sa[c0 + t] = a;
       sb[c0 + t] = b;
     }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * QCH, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * QCH, 0);
   }
+  ATTN_STAMP(1, sb[NKT - 1]);
+  // Invalid keys (rows past n_keys, staged as copies of row 0) get -inf: unconditionally on the tiles that may hold one -
+  // a wave-uniform branch per tile costs more than the eight selects (its hoisted masks live in spilled SGPRs).
   float mxa = -INFINITY, mxb = -INFINITY;
+  int lane_key = 4 * fg;
+  asm volatile("" : "+v"(lane_key));   // keeps the compares inside the pair loop: hoisted, the 4 masks per tile spill
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
-    if (kt * 16 + 16 > p.n_keys) {
-      asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch: full tiles skip the masks
+    if (kt >= FULL) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool ok = kt * 16 + 4 * fg + r < p.n_keys;
+        const bool ok = kt * 16 + lane_key + r < p.n_keys;
         sa[kt][r] = ok ? sa[kt][r] : -INFINITY;
         sb[kt][r] = ok ? sb[kt][r] : -INFINITY;
       }
@@ -152,9 +154,9 @@ __device__ __forceinline__ void pair_compute(const AttnParams& p, unsigned ks, u
     mxa = fmaxf(fmaxf(mxa, sa[kt][0]), fmaxf(sa[kt][1], fmaxf(sa[kt][2], sa[kt][3])));
     mxb = fmaxf(fmaxf(mxb, sb[kt][0]), fmaxf(sb[kt][1], fmaxf(sb[kt][2], sb[kt][3])));
   }
-  mxa = fmaxf(mxa, __shfl_xor(mxa, 16, 64)); mxb = fmaxf(mxb, __shfl_xor(mxb, 16, 64));
-  mxa = fmaxf(mxa, __shfl_xor(mxa, 32, 64)); mxb = fmaxf(mxb, __shfl_xor(mxb, 32, 64));
+  mxa = max_across_lane_groups(mxa); mxb = max_across_lane_groups(mxb);
   const float mna = -mxa * LOG2E, mnb = -mxb * LOG2E;
+  ATTN_STAMP(2, mnb);
   float suma = 0.f, sumb = 0.f;
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt)
@@ -166,6 +168,7 @@ __device__ __forceinline__ void pair_compute(const AttnParams& p, unsigned ks, u
       if (!GAVA_ATTN_ONESUM) { suma += ea; sumb += eb; }
     }
 
+  ATTN_STAMP(3, sb[NKT - 1]);
   // O^T = V^T P^T: every transposed V read of a batch is in flight before its MFMAs.
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) { oa[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; ob[dt] = oa[dt]; }
@@ -175,9 +178,6 @@ __device__ __forceinline__ void pair_compute(const AttnParams& p, unsigned ks, u
   const unsigned short one = P::cvt(1.0f);
   const s16x8_t ones = {(short)one, (short)one, (short)one, (short)one, (short)one, (short)one, (short)one, (short)one};
   constexpr int NC2 = NKT / 2;                       // 32-key chunks
-  unsigned va[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) va[dt] = vs + fa.v[dt];
 #pragma unroll
   for (int b0 = 0; b0 < NC2; b0 += PCH) {
     const int nb = NC2 - b0 < PCH ? NC2 - b0 : PCH;  // compile-time after unrolling
@@ -187,8 +187,9 @@ __device__ __forceinline__ void pair_compute(const AttnParams& p, unsigned ks, u
       if (c < nb) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          t0[c][dt] = lds_tr_b64(va[dt], (b0 + c) * 32 * LDS_ROW);
-          t1[c][dt] = lds_tr_b64(va[dt], (b0 + c) * 32 * LDS_ROW + 16 * LDS_ROW);
+          const char* vb = vs + fa.v[dt] + (b0 + c) * 32 * LDS_ROW;
+          t0[c][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb));
+          t1[c][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + 16 * LDS_ROW));
         }
       }
     }
@@ -196,7 +197,6 @@ __device__ __forceinline__ void pair_compute(const AttnParams& p, unsigned ks, u
     for (int c = 0; c < PCH; ++c) {
       if (c < nb) {
         const int cc = b0 + c;
-        lgkm_wait(8 * (nb - 1 - c), t0[c], t1[c]);
         const uint2 la = pack4<P>(sa[2 * cc][0], sa[2 * cc][1], sa[2 * cc][2], sa[2 * cc][3]);
         const uint2 ha = pack4<P>(sa[2 * cc + 1][0], sa[2 * cc + 1][1], sa[2 * cc + 1][2], sa[2 * cc + 1][3]);
         const uint2 lb = pack4<P>(sb[2 * cc][0], sb[2 * cc][1], sb[2 * cc][2], sb[2 * cc][3]);
@@ -223,6 +223,8 @@ __device__ __forceinline__ void pair_compute(const AttnParams& p, unsigned ks, u
     sumb = sum_across_lane_groups(sumb);
   }
   inva = __builtin_amdgcn_rcpf(suma); invb = __builtin_amdgcn_rcpf(sumb);
+  ATTN_STAMP(4, ob[3]);
+#undef ATTN_STAMP
 }
 
 // O^T leaves each lane with 4 consecutive head-dim columns of its own query: 8-byte stores.
@@ -252,7 +254,7 @@ __device__ __forceinline__ const unsigned short* q_row_ptr(const AttnParams& p, 
 
 // One workgroup (4 waves) per (problem, head), two workgroups per CU: 2 x 56 KiB of LDS at 224 keys, 2 x 80 KiB (all of
 // it) for the 320-key class (ViT-L/14 with T = 32).
-template <class P, int NKT, bool CAUSAL, bool PAIR = false>
+template <class P, int NKT, bool CAUSAL, bool PAIR = false, int FULL = 0>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
   constexpr int NWV = 4;
   constexpr int KP = NKT * 16;
@@ -293,7 +295,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
   if (p.dbg) t_staged = clock64();
 
   const FragAddr fa = frag_addr(fr, fg);
-  const unsigned ks = lds_addr(Ks), vs = lds_addr(Vs);
+  const char* ks = Ks;
+  const char* vs = Vs;
 
   if constexpr (PAIR) {
     // Tiles 2*pr and 2*pr+1; pairs are dealt round-robin to the 4 waves.
@@ -310,7 +313,16 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
       }
       f32x4_t oa[4], ob[4];
       float inva, invb;
-      pair_compute<P, NKT>(p, ks, vs, fa, fg, q0, q1, qb0, qb1, oa, ob, inva, invb);
+#ifdef GAVA_ATTN_STAMPS
+      unsigned long long st[5] = {0, 0, 0, 0, 0};
+      pair_compute<P, NKT, FULL>(p, ks, vs, fa, fg, q0, q1, qb0, qb1, oa, ob, inva, invb, p.dbg && pr == wave ? st : nullptr);
+      if (p.dbg && pr == wave && lane == 0 && blockIdx.x < 4096) {
+        unsigned long long* d = p.dbg + 4096 * 16 + (size_t)(blockIdx.x * 4 + wave) * 4;
+        for (int i = 0; i < 4; ++i) d[i] = st[i + 1] - st[i];
+      }
+#else
+      pair_compute<P, NKT, FULL>(p, ks, vs, fa, fg, q0, q1, qb0, qb1, oa, ob, inva, invb);
+#endif
       pair_store<P>(p, n, h, pr, fr, fg, oa, ob, inva, invb);
       q0 = na0; q1 = na1; qb0 = nb0; qb1 = nb1;
     }
@@ -329,23 +341,25 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     // compiler otherwise emits read -> wait -> 2 MFMA per tile and exposes the LDS latency 14 times).
     f32x4_t s[NKT];
     constexpr int QCH = NKT <= 14 ? NKT : NKT / 2;
-    const unsigned ka0 = ks + fa.k0, ka1 = ks + fa.k1;
+    const char* ka0 = ks + fa.k0;
+    const char* ka1 = ks + fa.k1;
 #pragma unroll
     for (int c0 = 0; c0 < NKT; c0 += QCH) {
       s16x8_t kf[QCH][2];
 #pragma unroll
       for (int t = 0; t < QCH; ++t) {
-        kf[t][0] = lds_b128(ka0, (c0 + t) * 16 * LDS_ROW);
-        kf[t][1] = lds_b128(ka1, (c0 + t) * 16 * LDS_ROW);
+        kf[t][0] = *reinterpret_cast<const s16x8_t*>(ka0 + (c0 + t) * 16 * LDS_ROW);
+        kf[t][1] = *reinterpret_cast<const s16x8_t*>(ka1 + (c0 + t) * 16 * LDS_ROW);
       }
 #pragma unroll
       for (int t = 0; t < QCH; ++t) {
-        lgkm_wait(2 * (QCH - 1 - t), kf[t][0], kf[t][1]);
         f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         a = P::mfma(kf[t][0], q0, a);
         a = P::mfma(kf[t][1], q1, a);
         s[c0 + t] = a;
       }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * QCH, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * QCH, 0);
     }
     // mask only the key tiles that can hold invalid keys (wave-uniform test), then row max
     float mx = -INFINITY;
@@ -363,8 +377,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
       }
       mx = fmaxf(fmaxf(mx, s[kt][0]), fmaxf(s[kt][1], fmaxf(s[kt][2], s[kt][3])));
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = max_across_lane_groups(mx);
     const float mneg = -mx * LOG2E;
     float sum = 0.f;
 #pragma unroll
@@ -385,9 +398,6 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     constexpr int NC2 = NKT / 2;                       // 32-key chunks
     constexpr int PCH = NC2 <= 7 ? NC2 : NC2 / 2;      // chunks per batch
-    unsigned va[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) va[dt] = vs + fa.v[dt];
 #pragma unroll
     for (int b0 = 0; b0 < NC2; b0 += PCH) {
       s16x4_t t0[PCH][4], t1[PCH][4];
@@ -395,14 +405,14 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
       for (int c = 0; c < PCH; ++c) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          t0[c][dt] = lds_tr_b64(va[dt], (b0 + c) * 32 * LDS_ROW);
-          t1[c][dt] = lds_tr_b64(va[dt], (b0 + c) * 32 * LDS_ROW + 16 * LDS_ROW);
+          const char* vb = vs + fa.v[dt] + (b0 + c) * 32 * LDS_ROW;
+          t0[c][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb));
+          t1[c][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, vb + 16 * LDS_ROW));
         }
       }
 #pragma unroll
       for (int c = 0; c < PCH; ++c) {
         const int cc = b0 + c;
-        lgkm_wait(8 * (PCH - 1 - c), t0[c], t1[c]);
         const uint2 lo = pack4<P>(s[2 * cc][0], s[2 * cc][1], s[2 * cc][2], s[2 * cc][3]);
         const uint2 hi = pack4<P>(s[2 * cc + 1][0], s[2 * cc + 1][1], s[2 * cc + 1][2], s[2 * cc + 1][3]);
         const s16x8_t pf = __builtin_bit_cast(s16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
@@ -412,6 +422,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
           o[dt] = P::mfma(vf, pf, o[dt]);
         }
       }
+      __builtin_amdgcn_sched_group_barrier(0x100, 8 * PCH, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * PCH, 0);
     }
     if (qi < p.n_q) {
       unsigned short* op = p.out + ((long)n * p.n_q + qi) * p.ldo + h * 64 + 4 * fg;
@@ -448,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
 // per wave (n_q <= 256).  One barrier per problem: a wave arrives after its own share of the next problem's loads has
 // landed (vmcnt(0) BEFORE its output stores, which then drain under the next problem) and after its last LDS read of the
 // current buffer, which is all the next iteration needs.
-template <class P, int NKT>
+template <class P, int NKT, int FULL>
 __global__ __launch_bounds__(512, 1) void attention_persist_kernel(const AttnParams p, const int n_prob) {
   constexpr int NWV = 8;
   constexpr int KP = NKT * 16;
@@ -461,7 +473,8 @@ __global__ __launch_bounds__(512, 1) void attention_persist_kernel(const AttnPar
   const int n_qt = (p.n_q + 15) >> 4;
   const bool has_pair = 2 * wave < n_qt;
   const FragAddr fa = frag_addr(fr, fg);
-  const unsigned ks = lds_addr(Ks), vs = lds_addr(Vs);
+  const char* ks = Ks;
+  const char* vs = Vs;
 
   int prob = blockIdx.x;
   if (prob >= n_prob) return;
@@ -500,7 +513,7 @@ __global__ __launch_bounds__(512, 1) void attention_persist_kernel(const AttnPar
     if (has_pair) {
       f32x4_t oa[4], ob[4];
       float inva, invb;
-      pair_compute<P, NKT, GAVA_PERSIST_PCH>(p, ks + buf * BUF, vs + buf * BUF, fa, fg, q0, q1, qb0, qb1, oa, ob, inva, invb);
+      pair_compute<P, NKT, FULL, GAVA_PERSIST_PCH>(p, ks + buf * BUF, vs + buf * BUF, fa, fg, q0, q1, qb0, qb1, oa, ob, inva, invb);
       // the next problem's K/V pieces and Q fragments of this wave have landed; nothing of this problem is stored yet
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(na0), "+v"(na1), "+v"(nb0), "+v"(nb1) : : "memory");
       pair_store<P>(p, n, h, wave, fr, fg, oa, ob, inva, invb);
@@ -534,20 +547,25 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 8;
   }
   if (persist_ok && pair && tiles > 6 && tiles <= 14 && p.n_q <= 256 && !p.dbg && n_prob >= 4 * n_cu) {
-    hipLaunchKernelGGL((attention_persist_kernel<P, 14>), dim3(n_cu), dim3(512), 0, s, p, n_prob);
+    if (tiles == 14) hipLaunchKernelGGL((attention_persist_kernel<P, 14, 13>), dim3(n_cu), dim3(512), 0, s, p, n_prob);
+    else hipLaunchKernelGGL((attention_persist_kernel<P, 14, 6>), dim3(n_cu), dim3(512), 0, s, p, n_prob);
     GAVA_CHECK_LAUNCH();
     return GAVA_OK;
   }
-#define GAVA_ATTN(N)                                                                              \
+  // (N, LOW): LOW = tile count of the class below, so tiles 0 .. LOW-1 are full; tiles == N: only the last can be partial
+#define GAVA_ATTN(N, LOW)                                                                         \
   do {                                                                                            \
     if (p.causal) hipLaunchKernelGGL((attention_kernel<P, N, true, false>), grid, blk, 0, s, p);  \
-    else if (pair && N >= 14) hipLaunchKernelGGL((attention_kernel<P, (N >= 14 ? N : 14), false, true>), grid, blk, 0, s, p); \
+    else if (pair && N >= 14 && tiles == N)                                                       \
+      hipLaunchKernelGGL((attention_kernel<P, (N >= 14 ? N : 14), false, true, (N >= 14 ? N : 14) - 1>), grid, blk, 0, s, p); \
+    else if (pair && N >= 14)                                                                     \
+      hipLaunchKernelGGL((attention_kernel<P, (N >= 14 ? N : 14), false, true, (N >= 14 ? LOW : 6)>), grid, blk, 0, s, p); \
     else hipLaunchKernelGGL((attention_kernel<P, N, false, false>), grid, blk, 0, s, p);          \
   } while (0)
-  if (tiles <= 2) GAVA_ATTN(2);
-  else if (tiles <= 6) GAVA_ATTN(6);
-  else if (tiles <= 14) GAVA_ATTN(14);
-  else if (tiles <= 20) GAVA_ATTN(20);
+  if (tiles <= 2) GAVA_ATTN(2, 0);
+  else if (tiles <= 6) GAVA_ATTN(6, 2);
+  else if (tiles <= 14) GAVA_ATTN(14, 6);
+  else if (tiles <= 20) GAVA_ATTN(20, 14);
   else return GAVA_EINVAL;
 #undef GAVA_ATTN
   GAVA_CHECK_LAUNCH();

@@ -84,6 +84,13 @@ static __device__ __forceinline__ float sum_across_lane_groups(float x) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+static __device__ __forceinline__ float max_across_lane_groups(float x) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -7,7 +7,8 @@ import torch
 from gava_clip_amd import hip
 lib = hip.load()
 lib.gava_debug_set_buffer.argtypes = [C.c_void_p]
-D, H, T, G, n1, BT = 768, 12, 8, 8, 197, 512
+D, H, T, G, n1 = 768, 12, 8, 8, 197
+BT = int(sys.argv[1]) if len(sys.argv) > 1 else 512     # 16 frames x 12 heads = 192 workgroups: one per CU, waves alone on their SIMD
 R = BT * n1
 g = torch.Generator(device="cuda").manual_seed(1)
 rn = lambda *s: torch.randn(*s, device="cuda", generator=g).half()
@@ -15,10 +16,14 @@ QKV, side, O = rn(R, 3 * D), rn(G + 2 * BT, 2 * D), torch.empty(R, D, dtype=torc
 fn = lambda: hip.attention(QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, batch=BT, heads=H, n_q=n1, n_kmain=n1, prec=0,
                            side_k=side[:, :D], side_v=side[:, D:], n_g=G, T=T, has_summary=True)
 for _ in range(10): fn()
-dbg = torch.zeros(4096 * 4 * 4, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(2 * 4096 * 4 * 4, dtype=torch.int64, device="cuda")
 lib.gava_debug_set_buffer(C.c_void_p(dbg.data_ptr()))
 fn(); torch.cuda.synchronize()
 lib.gava_debug_set_buffer(None)
-d = dbg.view(4096, 4, 4).double()
+nwg = min(4096, BT * H)
+ph = dbg[4096 * 16:].view(4096, 4, 4)[:nwg].double()
+d = dbg[:4096 * 16].view(4096, 4, 4)[:nwg].double()
+if ph.sum() > 0:   # -DGAVA_ATTN_STAMPS build: phases of a wave's first query-tile pair
+    print("first pair, cycles: K Q^T %.0f | mask + row max %.0f | exp %.0f | P V (+ row sums) %.0f" % tuple(ph[..., i].mean() for i in range(4)))
 print("per wave cycles: issue+wait K/V,Q loads %.0f | LDS write + barrier %.0f | compute %.0f (%.1f q-tiles => %.0f / q-tile)" % (
     d[..., 0].mean(), d[..., 1].mean(), d[..., 2].mean(), d[..., 3].mean(), (d[..., 2] / d[..., 3]).mean()))
