@@ -1,10 +1,19 @@
 // attention.hip — fused softmax(Q K^T) V, head dim 64, 16-bit MFMA operands, fp32 softmax.
 //
-// gfx950 design: one workgroup (4 waves) per (problem, head).  The whole key set of a problem is
-// short (<= 320 keys: 214 for ViT-B/16 with T=8), so K and V of one head are staged ONCE in LDS by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers, no ds_write pass; 128-byte rows whose 16-byte chunks are XOR-swizzled by
-// row & 6 on the source address - found by search to be conflict-free for both the ds_read_b128 K-fragment reads and the
-// ds_read_b64_tr_b16 transposed V reads) and softmax is single pass: no online rescaling.
+// gfx950 design: a problem is one (frame, head).  Its whole key set is short (<= 320 keys: 214 for ViT-B/16 with T=8), so
+// K and V of one head are staged ONCE in LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass;
+// 128-byte rows whose 16-byte chunks are XOR-swizzled by row & 6 on the source address - found by search to be
+// conflict-free for both the ds_read_b128 K-fragment reads and the ds_read_b64_tr_b16 transposed V reads) and softmax is
+// single pass: no online rescaling.  Two kernels: attention_kernel, one 4-wave workgroup per problem (two per CU), and
+// attention_persist_kernel for the vision blocks at 209..224 keys, one 8-wave workgroup per CU walking the problems with
+// K/V double-buffered and the next problem staged by the wave that has no query tiles (see there).
+// Round-2 measurements behind the present form (tools/attn_stamps.py, tools/r2_attn_ab.sh; ViT-B/16 T=8 B=64, 0.200 ms
+// before): loads alone 0.072 ms, compute alone 0.158 ms, so the load phase was only partly hidden by the CU's second
+// workgroup -> persistent + prefetch; per-tile mask branches cost 750 of a pair's 5900 cycles -> branch-free masks on the
+// tiles that can need them; 56 LDS-DMA issues per problem take ~3000 cycles to be accepted -> one loader wave; the kernel
+// now moves its 650 MB at 4.0 TB/s (0.162 ms).  Tried and dropped: K first / V later staging with a second barrier (slower),
+// a two-block online-softmax order that interleaves MFMAs with the exp/max VALU work inside a wave (instruction order
+// verified in the ISA; 5 % slower than the plain phase order), 8 waves per workgroup for the 320-key class.
 // Per 16-query tile a wave computes S^T = K Q^T with the KEY on the MFMA row, so every lane
 // holds, for its own query (lane&15), 4 consecutive keys per 16-key tile.  That accumulator
 // layout is already the B-operand layout of the second product O^T = V^T P^T (k-slot order
@@ -70,6 +79,85 @@ __device__ __forceinline__ void stage_kv(const AttnParams& p, int n, int h, char
       dma16(kb + off, lds_addr(Ks) + dst);
       dma16(vb + off, lds_addr(Vs) + dst);
     }
+  }
+}
+
+// The same transfer for a kernel that stages many problems: everything that does not depend on the problem is worked out
+// once per thread (measured in the persistent kernel: recomputing the row -> source map, with its integer division and
+// 64-bit multiplies, for every problem took 2500-4000 cycles of a 12000-cycle problem).  Per 16-byte piece a 32-bit
+// element offset and a 2-bit source type; per problem four wave-uniform base pointers per matrix (scalar unit).
+//   type 0: main row (n n_kmain + row) of k/v     1: global prompt row of side_k/v
+//   type 2: local prompt row, + (n / T) T rows    3: summary row, + n rows
+template <int KP, int NTH>
+struct StagePlan {
+  static constexpr int NIT = (KP * 8 + NTH - 1) / NTH;
+  int coff[NIT];
+  unsigned types;
+};
+template <int KP, int NTH>
+__device__ __forceinline__ StagePlan<KP, NTH> make_stage_plan(const AttnParams& p, int tid) {
+  StagePlan<KP, NTH> pl;
+  pl.types = 0;
+#pragma unroll
+  for (int it = 0; it < pl.NIT; ++it) {
+    const int id = tid + it * NTH;
+    const int row = id >> 3, chunk = (id & 7) ^ (row & 6);
+    const int rowc = row < p.n_keys ? row : 0;
+    const int sidx = rowc - p.n_kmain;
+    const int typ = sidx < 0 ? 0 : sidx < p.n_g ? 1 : sidx < p.n_g + p.T ? 2 : 3;
+    pl.coff[it] = (typ == 0 ? rowc * (int)p.ld : typ == 3 ? (p.n_g + p.batch) * (int)p.lds : sidx * (int)p.lds) + chunk * 8;
+    pl.types |= (unsigned)typ << (2 * it);
+  }
+  return pl;
+}
+template <int KP, int NTH>
+__device__ __forceinline__ void issue_stage_plan(const StagePlan<KP, NTH>& pl, const AttnParams& p, int n, int h,
+                                                 char* Ks, char* Vs, int tid, int wave) {
+  const long o0 = (long)n * p.n_kmain * p.ld + h * 64, o1 = h * 64, o2 = (long)(n / p.T) * p.T * p.lds + h * 64,
+             o3 = (long)n * p.lds + h * 64;
+  const unsigned short* kb[4] = {p.k + o0, p.sk + o1, p.sk + o2, p.sk + o3};
+  const unsigned short* vb[4] = {p.v + o0, p.sv + o1, p.sv + o2, p.sv + o3};
+#pragma unroll
+  for (int it = 0; it < pl.NIT; ++it) {
+    if (tid + it * NTH < KP * 8) {                                     // wave-uniform: KP * 8 is a multiple of 64
+      const unsigned typ = (pl.types >> (2 * it)) & 3;
+      const unsigned short* ksrc = (typ == 0 ? kb[0] : typ == 1 ? kb[1] : typ == 2 ? kb[2] : kb[3]) + pl.coff[it];
+      const unsigned short* vsrc = (typ == 0 ? vb[0] : typ == 1 ? vb[1] : typ == 2 ? vb[2] : vb[3]) + pl.coff[it];
+      const int dst = (wave * 64 + it * NTH) * 16;
+      dma16(ksrc, lds_addr(Ks) + dst);
+      dma16(vsrc, lds_addr(Vs) + dst);
+    }
+  }
+}
+
+// One wave stages a whole problem (the persistent kernel's loader wave): 1 KiB pieces of 8 rows each.  Pieces that lie
+// entirely in the main rows advance two pointers by 8 rows; the few pieces with prompt/summary/padding rows take the
+// general row -> source map of stage_kv.
+template <int KP>
+__device__ __forceinline__ void stage_kv_one_wave(const AttnParams& p, int n, int h, char* Ks, char* Vs, int lane) {
+  const int r8 = lane >> 3, chunk = (lane & 7) ^ (r8 & 6);           // row & 6 == r8 & 6: pieces start at multiples of 8
+  const int n_fast = p.n_kmain >> 3;
+  const long o_main = ((long)n * p.n_kmain + r8) * p.ld + h * 64 + chunk * 8;
+  const unsigned short* kp = p.k + o_main;
+  const unsigned short* vp = p.v + o_main;
+  const unsigned kdst = lds_addr(Ks), vdst = lds_addr(Vs);
+  int j = 0;
+  for (; j < n_fast; ++j) {
+    dma16(kp, kdst + j * 1024);
+    dma16(vp, vdst + j * 1024);
+    kp += 8 * p.ld; vp += 8 * p.ld;
+  }
+  for (; j < KP / 8; ++j) {
+    const int row = j * 8 + r8;
+    const int rowc = row < p.n_keys ? row : 0;
+    const int sidx = rowc - p.n_kmain;                               // >= 0: side row
+    const long sr = sidx < p.n_g ? sidx
+                  : sidx < p.n_g + p.T ? p.n_g + (long)(n / p.T) * p.T + (sidx - p.n_g)
+                                       : (long)p.n_g + p.batch + n;
+    const bool is_main = rowc < p.n_kmain;
+    const long off = (is_main ? ((long)n * p.n_kmain + rowc) * p.ld : sr * p.lds) + h * 64 + chunk * 8;
+    dma16((is_main ? p.k : p.sk) + off, kdst + j * 1024);
+    dma16((is_main ? p.v : p.sv) + off, vdst + j * 1024);
   }
 }
 
@@ -229,21 +317,25 @@ __device__ __forceinline__ void pair_compute(const AttnParams& p, const char* ks
 
 // O^T leaves each lane with 4 consecutive head-dim columns of its own query: 8-byte stores.
 template <class P>
+__device__ __forceinline__ void pair_store_at(unsigned short* opa, bool valid_a, unsigned short* opb, bool valid_b,
+                                              const f32x4_t (&oa)[4], const f32x4_t (&ob)[4], float inva, float invb) {
+  if (valid_a) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<uint2*>(opa + dt * 16) = pack4<P>(oa[dt][0] * inva, oa[dt][1] * inva, oa[dt][2] * inva, oa[dt][3] * inva);
+  }
+  if (valid_b) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<uint2*>(opb + dt * 16) = pack4<P>(ob[dt][0] * invb, ob[dt][1] * invb, ob[dt][2] * invb, ob[dt][3] * invb);
+  }
+}
+template <class P>
 __device__ __forceinline__ void pair_store(const AttnParams& p, int n, int h, int pr, int fr, int fg,
                                            const f32x4_t (&oa)[4], const f32x4_t (&ob)[4], float inva, float invb) {
   const int qia = pr * 32 + fr, qib = qia + 16;
-  if (qia < p.n_q) {
-    unsigned short* op = p.out + ((long)n * p.n_q + qia) * p.ldo + h * 64 + 4 * fg;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<uint2*>(op + dt * 16) = pack4<P>(oa[dt][0] * inva, oa[dt][1] * inva, oa[dt][2] * inva, oa[dt][3] * inva);
-  }
-  if (qib < p.n_q) {
-    unsigned short* op = p.out + ((long)n * p.n_q + qib) * p.ldo + h * 64 + 4 * fg;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<uint2*>(op + dt * 16) = pack4<P>(ob[dt][0] * invb, ob[dt][1] * invb, ob[dt][2] * invb, ob[dt][3] * invb);
-  }
+  pair_store_at<P>(p.out + ((long)n * p.n_q + qia) * p.ldo + h * 64 + 4 * fg, qia < p.n_q,
+                   p.out + ((long)n * p.n_q + qib) * p.ldo + h * 64 + 4 * fg, qib < p.n_q, oa, ob, inva, invb);
 }
 
 __device__ __forceinline__ const unsigned short* q_row_ptr(const AttnParams& p, int n, int h, int qt, int fr, int fg) {
@@ -479,20 +571,45 @@ __global__ __launch_bounds__(512, 1) void attention_persist_kernel(const AttnPar
   int prob = blockIdx.x;
   if (prob >= n_prob) return;
   int n = prob / p.heads, h = prob - n * p.heads;
+  // problem-independent parts of every address this thread forms, once
+  const StagePlan<KP, NWV * 64> plan = make_stage_plan<KP, NWV * 64>(p, tid);
+  const int qia = wave * 32 + fr, qib = qia + 16;
+  const int qoa = (qia < p.n_q ? qia : p.n_q - 1) * (int)p.ldq + 8 * fg;   // a tile beyond n_q computes garbage, stores nothing
+  const int qob = (qib < p.n_q ? qib : p.n_q - 1) * (int)p.ldq + 8 * fg;
+  const int ooa = qia * (int)p.ldo + 4 * fg, oob = qib * (int)p.ldo + 4 * fg;
+  const bool valid_a = qia < p.n_q, valid_b = qib < p.n_q;
+  auto q_base = [&](int n_, int h_) { return p.q + ((long)n_ * p.qbr * p.ldq + h_ * 64); };
+  // With a wave to spare (7 pairs at 197 queries) that wave alone issues the next problem's K/V: 56 LDS-DMA instructions
+  // take ~3000 cycles to get accepted by the memory pipeline (measured), which the computing waves would otherwise all
+  // spend at the top of every problem before their first MFMA.
+  const bool use_loader = (n_qt + 1) / 2 < NWV;
+  auto stage = [&](int n_, int h_, char* kd, char* vd) {
+    if (use_loader) {
+      if (wave == NWV - 1) stage_kv_one_wave<KP>(p, n_, h_, kd, vd, lane);
+    } else {
+      issue_stage_plan(plan, p, n_, h_, kd, vd, tid, wave);
+    }
+  };
   s16x8_t q0 = {0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, qb0 = q0, qb1 = q0;
-  stage_kv<KP, NWV * 64>(p, n, h, Ks, Vs, tid, wave);
+  stage(n, h, Ks, Vs);
   if (has_pair) {
-    const unsigned short* qp = q_row_ptr(p, n, h, 2 * wave, fr, fg);
-    q0 = *reinterpret_cast<const s16x8_t*>(qp);
-    q1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
-    const unsigned short* qq = q_row_ptr(p, n, h, 2 * wave + 1, fr, fg);
-    qb0 = *reinterpret_cast<const s16x8_t*>(qq);
-    qb1 = *reinterpret_cast<const s16x8_t*>(qq + 32);
+    const unsigned short* qp = q_base(n, h);
+    q0 = *reinterpret_cast<const s16x8_t*>(qp + qoa);
+    q1 = *reinterpret_cast<const s16x8_t*>(qp + qoa + 32);
+    qb0 = *reinterpret_cast<const s16x8_t*>(qp + qob);
+    qb1 = *reinterpret_cast<const s16x8_t*>(qp + qob + 32);
   }
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(qb0), "+v"(qb1) : : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
+#ifdef GAVA_ATTN_STAMPS   // per-wave sums over the problems: issue | compute | wait for the prefetch | stores | barrier
+  unsigned long long acc[5] = {0, 0, 0, 0, 0}, tp = clock64();
+  const unsigned long long w0 = wall_clock64(), c0 = tp;
+#define PSTAMP(i) do { const unsigned long long t = clock64(); acc[i] += t - tp; tp = t; } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
   int buf = 0;
   for (;;) {
     const int nxt = prob + gridDim.x;
@@ -500,32 +617,48 @@ __global__ __launch_bounds__(512, 1) void attention_persist_kernel(const AttnPar
     const int nn = nxt / p.heads, nh = nxt - nn * p.heads;
     s16x8_t na0 = q0, na1 = q1, nb0 = qb0, nb1 = qb1;
     if (more) {
-      stage_kv<KP, NWV * 64>(p, nn, nh, Ks + (buf ^ 1) * BUF, Vs + (buf ^ 1) * BUF, tid, wave);
+      stage(nn, nh, Ks + (buf ^ 1) * BUF, Vs + (buf ^ 1) * BUF);
       if (has_pair) {
-        const unsigned short* qp = q_row_ptr(p, nn, nh, 2 * wave, fr, fg);
-        na0 = *reinterpret_cast<const s16x8_t*>(qp);
-        na1 = *reinterpret_cast<const s16x8_t*>(qp + 32);
-        const unsigned short* qq = q_row_ptr(p, nn, nh, 2 * wave + 1, fr, fg);
-        nb0 = *reinterpret_cast<const s16x8_t*>(qq);
-        nb1 = *reinterpret_cast<const s16x8_t*>(qq + 32);
+        const unsigned short* qp = q_base(nn, nh);
+        na0 = *reinterpret_cast<const s16x8_t*>(qp + qoa);
+        na1 = *reinterpret_cast<const s16x8_t*>(qp + qoa + 32);
+        nb0 = *reinterpret_cast<const s16x8_t*>(qp + qob);
+        nb1 = *reinterpret_cast<const s16x8_t*>(qp + qob + 32);
       }
     }
+    PSTAMP(0);
     if (has_pair) {
       f32x4_t oa[4], ob[4];
       float inva, invb;
       pair_compute<P, NKT, FULL, GAVA_PERSIST_PCH>(p, ks + buf * BUF, vs + buf * BUF, fa, fg, q0, q1, qb0, qb1, oa, ob, inva, invb);
+#ifdef GAVA_ATTN_STAMPS
+      asm volatile("" :: "v"(ob[3]), "v"(inva), "v"(invb));
+#endif
+      PSTAMP(1);
       // the next problem's K/V pieces and Q fragments of this wave have landed; nothing of this problem is stored yet
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(na0), "+v"(na1), "+v"(nb0), "+v"(nb1) : : "memory");
-      pair_store<P>(p, n, h, wave, fr, fg, oa, ob, inva, invb);
+      PSTAMP(2);
+      unsigned short* ob_ = p.out + ((long)n * p.n_q * p.ldo + h * 64);
+      pair_store_at<P>(ob_ + ooa, valid_a, ob_ + oob, valid_b, oa, ob, inva, invb);
+      PSTAMP(3);
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    PSTAMP(4);
     if (!more) break;
     q0 = na0; q1 = na1; qb0 = nb0; qb1 = nb1;
     prob = nxt; n = nn; h = nh; buf ^= 1;
   }
+#ifdef GAVA_ATTN_STAMPS
+  if (p.dbg && lane == 0) {
+    unsigned long long* d = p.dbg + (size_t)(blockIdx.x * 8 + wave) * 8;
+    for (int i = 0; i < 5; ++i) d[i] = acc[i];
+    d[5] = clock64() - c0; d[6] = wall_clock64() - w0; d[7] = (n_prob - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  }
+#endif
+#undef PSTAMP
 }
 
 template <class P>
@@ -536,8 +669,8 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
   // two query tiles per wave for the big non-causal problems (vision blocks); GAVA_ATTN_PAIR=0 turns it off (A/B)
   static const bool pair_ok = !(getenv("GAVA_ATTN_PAIR") && getenv("GAVA_ATTN_PAIR")[0] == '0');
   const bool pair = pair_ok && !p.causal && !p.split && p.n_q >= 64;
-  // persistent double-buffered form: the 224-key class with at most 8 query-tile pairs, enough problems to keep every CU
-  // busy for several rounds; GAVA_ATTN_PERSIST=0 turns it off (A/B)
+  // persistent double-buffered form: 209..224 keys (14 key tiles, only the last can be partial) with at most 8 query-tile
+  // pairs, and enough problems to keep every CU busy for several rounds; GAVA_ATTN_PERSIST=0 turns it off (A/B)
   static const bool persist_ok = !(getenv("GAVA_ATTN_PERSIST") && getenv("GAVA_ATTN_PERSIST")[0] == '0');
   static int n_cu = 0;
   if (!n_cu) {
@@ -546,9 +679,13 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GAVA_ELAUNCH;
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 8;
   }
-  if (persist_ok && pair && tiles > 6 && tiles <= 14 && p.n_q <= 256 && !p.dbg && n_prob >= 4 * n_cu) {
-    if (tiles == 14) hipLaunchKernelGGL((attention_persist_kernel<P, 14, 13>), dim3(n_cu), dim3(512), 0, s, p, n_prob);
-    else hipLaunchKernelGGL((attention_persist_kernel<P, 14, 6>), dim3(n_cu), dim3(512), 0, s, p, n_prob);
+  #ifdef GAVA_ATTN_STAMPS
+  const bool dbg_ok = true;
+#else
+  const bool dbg_ok = !p.dbg;
+#endif
+  if (persist_ok && pair && tiles == 14 && p.n_q <= 256 && dbg_ok && n_prob >= 4 * n_cu) {
+    hipLaunchKernelGGL((attention_persist_kernel<P, 14, 13>), dim3(n_cu), dim3(512), 0, s, p, n_prob);
     GAVA_CHECK_LAUNCH();
     return GAVA_OK;
   }

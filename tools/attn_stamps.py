@@ -20,6 +20,18 @@ dbg = torch.zeros(2 * 4096 * 4 * 4, dtype=torch.int64, device="cuda")
 lib.gava_debug_set_buffer(C.c_void_p(dbg.data_ptr()))
 fn(); torch.cuda.synchronize()
 lib.gava_debug_set_buffer(None)
+if BT * H >= 1024 and os.environ.get("GAVA_ATTN_PERSIST", "1") != "0" and os.environ.get("GAVA_HIP_LIB", "").endswith("stamps.so"):
+    # persistent kernel (stamps build): per-wave sums over its problems
+    d = dbg[:256 * 8 * 8].view(256, 8, 8).double()
+    npb = d[..., 7].mean()
+    for name, sl in (("waves 0-6 (one pair each)", slice(0, 7)), ("wave 7 (no pair)", slice(7, 8))):
+        x = d[:, sl].reshape(-1, 8)
+        print("%s, cycles per problem: issue next loads %.0f | compute %.0f | wait prefetch %.0f | stores %.0f | barrier %.0f | total %.0f; clock %.2f GHz" % (
+            name, *(x[:, i].mean() / npb for i in range(5)), x[:, 5].mean() / npb, x[:, 5].mean() / x[:, 6].mean() * 0.1))
+    for w in range(8):
+        x = d[:, w]
+        print("  wave %d: issue %.0f compute %.0f wait %.0f stores %.0f barrier %.0f" % (w, *(x[:, i].mean() / npb for i in range(5))))
+    sys.exit(0)
 nwg = min(4096, BT * H)
 ph = dbg[4096 * 16:].view(4096, 4, 4)[:nwg].double()
 d = dbg[:4096 * 16].view(4096, 4, 4)[:nwg].double()

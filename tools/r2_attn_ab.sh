@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/r2
 python -m pytest tests/test_gpu_ops.py -q -x -k attention > gpurun_out/r2/attn_tests.log 2>&1 || { tail -30 gpurun_out/r2/attn_tests.log; exit 1; }
 tail -1 gpurun_out/r2/attn_tests.log
-[ -f gava_clip_amd/libgava_hip_stamps.so ] && GAVA_HIP_LIB=gava_clip_amd/libgava_hip_stamps.so python tools/attn_stamps.py 16 2>&1 | grep -v amdgpu.ids
+for l in stamps np_stamps; do [ -f gava_clip_amd/libgava_hip_$l.so ] && GAVA_HIP_LIB=gava_clip_amd/libgava_hip_$l.so python tools/attn_stamps.py 512 2>&1 | grep "cycles per problem"; done
 for r in 1 2 3; do
 for lib in "$@"; do
   L=gava_clip_amd/libgava_hip_$lib.so; [ $lib = new ] && L=gava_clip_amd/libgava_hip.so
