@@ -132,6 +132,24 @@ struct VisionWs {
 
 int patch_k(const gava_vision_model* m) { return (3 * m->P * m->P + 63) / 64 * 64; }
 
+// The A operand of the patch-embedding GEMM: the 16-bit patch matrix written into `scratch` (gava_patchify), or, with
+// GAVA_PATCH_DIRECT=1, the frames themselves for the GEMM's in-loop loaders.
+int patch_operand(const gava_vision_model* m, const float* x, void* scratch, int Kp, int prec, gava_stream_t stream,
+                  gava_gemm_args* a) {
+  static const bool direct = getenv("GAVA_PATCH_DIRECT") != nullptr;
+  a->lda = Kp; a->frame_size = m->size; a->patch = m->P;
+  if (direct) {
+    a->A = nullptr; a->frames = m->clips ? nullptr : x; a->clips = m->clips; a->clip_lut = m->clip_lut;
+    return GAVA_OK;
+  }
+  gava_patchify_args pa{};
+  pa.x = m->clips ? nullptr : x; pa.clips = m->clips; pa.clip_lut = m->clip_lut;
+  pa.B = m->B; pa.T = m->T_in; pa.size = m->size; pa.patch = m->P; pa.prec = prec;
+  pa.out = scratch; pa.ldo = Kp;
+  a->A = scratch;
+  return gava_patchify(&pa, stream);
+}
+
 VisionWs carve_vision(const gava_vision_model* m, void* ws, size_t cap) {
   const long g = m->size / m->P, n = g * g, BT = (long)m->B * m->T_in, R = BT * (n + 1);
   const long D = m->D, F = m->F, E = m->E, SR = m->G + 2 * BT;
@@ -141,7 +159,10 @@ VisionWs carve_vision(const gava_vision_model* m, void* ws, size_t cap) {
   w.Xn = c.take(R * D * 2);
   w.QKV = c.take(R * 3 * D * 2);
   w.MIX = c.take(R * D * 2);
-  w.HID = c.take((size_t)R * F * 2);
+  {  // the fc1 output; before the blocks it parks the 16-bit patch matrix (patch_operand)
+    const size_t hid = (size_t)R * F * 2, pm = (size_t)BT * n * patch_k(m) * 2;
+    w.HID = c.take(hid > pm ? hid : pm);
+  }
   w.CLS16 = c.take(BT * D * 2);
   w.CP = (float*)c.take(BT * D * 4);
   w.CPn = c.take(BT * D * 2);
@@ -224,10 +245,12 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
 
   // ---- embedding (VitaCLIP_vision_encoder.py:105-113)
   {
-    // im2col-free patch embedding: the GEMM builds its A tiles straight from the frames
+    // patch matrix in 16 bits first (one HBM-bound pass, parked in the still unused fc1 buffer), then a GEMM that stages it
+    // by LDS-DMA like every other operand: 0.25 ms instead of 0.38 ms for the loader that converted fp32 frames inside the
+    // k-loop, and 0.3 ms instead of 2.3 ms for the uint8 source (tools/kernel_bench.py patch / patchA / patchu8).
+    // GAVA_PATCH_DIRECT=1 keeps the in-loop loaders (A/B, and the op tests still cover them).
     gava_gemm_args a{};
-    a.A = nullptr; a.lda = Kp; a.frames = m->clips ? nullptr : x; a.frame_size = m->size; a.patch = m->P;
-    a.clips = m->clips; a.clip_lut = m->clip_lut;
+    TRY(patch_operand(m, x, w.HID, Kp, pr, stream, &a));
     a.W = m->w_patch; a.ldw = Kp; a.bias = m->b_patch;
     a.out = w.X; a.ldo = D; a.M = BT * n; a.N = D; a.K = Kp; a.epilogue = GAVA_EPI_F32_PATCH; a.prec = pr;
     a.pos = m->pos_embed; a.time = m->time_embed; a.n_patches = n; a.T = m->T_in;
@@ -421,8 +444,7 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
   const size_t RD = (size_t)R * D;
   {
     gava_gemm_args a{};
-    a.A = nullptr; a.lda = Kp; a.frames = m->clips ? nullptr : x; a.frame_size = m->size; a.patch = m->P;
-    a.clips = m->clips; a.clip_lut = m->clip_lut;
+    TRY(patch_operand(m, x, w.HID, Kp, pr, stream, &a));
     a.W = m->w_patch; a.ldw = Kp; a.bias = m->b_patch;
     a.out = sv->e0; a.ldo = D; a.M = BT * n; a.N = D; a.K = Kp; a.epilogue = GAVA_EPI_F32_PATCH; a.prec = pr;
     a.pos = m->pos_embed; a.time = m->time_embed; a.n_patches = n; a.T = m->T_in;

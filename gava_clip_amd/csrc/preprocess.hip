@@ -28,7 +28,88 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PrepParams p) {
         clip_pixel1(p.g.frames, p.g.height, p.g.width, p.g.h_st, p.g.w_st, p.g.scale_h, p.g.scale_w, p.lut, p.mean[c], p.std[c], f, c, y, x);
 }
 
+// Patch matrix (see gava_patchify_args): one workgroup per (patch row gy, channel c, frame f): P image rows of `size`
+// pixels in, g segments of P x P 16-bit values out.  VEC consecutive pixels per thread (4 when P % 4 == 0: 16-byte fp32
+// loads, 8-byte stores; 2 for P = 14): a vector never straddles a patch.
+struct PatchifyParams {
+  const float* x; const gava_clip_desc* clips; const float* lut;
+  unsigned short* out; long ldo;
+  int T, size, P, g;
+};
+
+template <class Pr, int VEC>
+__global__ __launch_bounds__(256) void patchify_kernel(const PatchifyParams p) {
+  const int gy = blockIdx.x, c = blockIdx.y, f = blockIdx.z;
+  const int b = f / p.T, t = f - b * p.T;
+  const int n_vec = p.P * p.size / VEC, PP = p.P * p.P;
+  const float* plane = nullptr;
+  ClipGeom cg{};
+  int fsrc = 0;
+  if (p.x) plane = p.x + (((long)b * 3 + c) * p.T + t) * p.size * p.size + (long)gy * p.P * p.size;
+  else {
+    const gava_clip_desc d = p.clips[b];
+    cg = ClipGeom{d.frames, d.n_frames, d.height, d.width, d.t_st, d.rate, d.h_st, d.w_st, d.scale_h, d.scale_w};
+    fsrc = d.t_st + t * d.rate;
+    fsrc = fsrc < d.n_frames ? fsrc : d.n_frames - 1;
+  }
+  unsigned short* orow0 = p.out + ((long)f * p.g * p.g + (long)gy * p.g) * p.ldo + c * PP;
+  for (int i = threadIdx.x; i < n_vec; i += 256) {
+    const int e0 = i * VEC, iy = e0 / p.size, x0 = e0 - iy * p.size;
+    float v[VEC];
+    if (p.x) {
+      if (VEC == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(plane + e0);
+        v[0] = q.x; v[1] = q.y; v[VEC - 2] = q.z; v[VEC - 1] = q.w;
+      } else {
+        const float2 q = *reinterpret_cast<const float2*>(plane + e0);
+        v[0] = q.x; v[1] = q.y;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        v[e] = clip_pixel1(cg.frames, cg.height, cg.width, cg.h_st, cg.w_st, cg.scale_h, cg.scale_w, p.lut, 0.f, 1.f, fsrc, c,
+                           gy * p.P + iy, x0 + e);
+    }
+    const int px = x0 / p.P, ix = x0 - px * p.P;
+    unsigned short* o = orow0 + (long)px * p.ldo + iy * p.P + ix;
+    if (VEC == 4) *reinterpret_cast<uint2*>(o) = pack4<Pr>(v[0], v[1], v[VEC - 2], v[VEC - 1]);
+    else *reinterpret_cast<unsigned*>(o) = Pr::cvt2(v[0], v[1]);
+  }
+  // zero the K padding of this patch row once (the c == 0 workgroup)
+  const int pad = (int)p.ldo - 3 * PP;
+  if (c == 0 && pad > 0) {
+    for (int i = threadIdx.x; i < p.g * pad; i += 256) {
+      const int px = i / pad, k = i - px * pad;
+      p.out[((long)f * p.g * p.g + (long)gy * p.g + px) * p.ldo + 3 * PP + k] = 0;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int gava_patchify(const gava_patchify_args* a, gava_stream_t stream) {
+  if (!a || !a->out || (!a->x && !a->clips) || (a->x && a->clips)) return GAVA_EINVAL;
+  if (a->clips && !a->clip_lut) return GAVA_EINVAL;
+  if (a->B <= 0 || a->T <= 0 || a->size <= 0 || a->patch <= 0 || a->size % a->patch || a->patch % 2) return GAVA_EINVAL;
+  if (a->ldo < 3 * a->patch * a->patch || a->ldo % 8 || ((uintptr_t)a->out & 15)) return GAVA_EINVAL;
+  if (a->x && (((uintptr_t)a->x & 15) || (a->patch % 4 == 0 && a->size % 4))) return GAVA_EINVAL;
+  PatchifyParams p;
+  p.x = a->x; p.clips = a->clips; p.lut = a->clip_lut;
+  p.out = (unsigned short*)a->out; p.ldo = a->ldo;
+  p.T = a->T; p.size = a->size; p.P = a->patch; p.g = a->size / a->patch;
+  dim3 grid(p.g, 3, a->B * a->T), block(256);
+  const bool v4 = a->patch % 4 == 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->prec == GAVA_PREC_F16) {
+    if (v4) hipLaunchKernelGGL((patchify_kernel<PrecF16, 4>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((patchify_kernel<PrecF16, 2>), grid, block, 0, s, p);
+  } else if (a->prec == GAVA_PREC_BF16) {
+    if (v4) hipLaunchKernelGGL((patchify_kernel<PrecBF16, 4>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((patchify_kernel<PrecBF16, 2>), grid, block, 0, s, p);
+  } else return GAVA_EINVAL;
+  if (hipGetLastError() != hipSuccess) return GAVA_ELAUNCH;
+  return GAVA_OK;
+}
 
 extern "C" int gava_clip_geometry(gava_clip_desc* d, int T, int rate, int size, int first_temporal_view, int first_spatial_view) {
   if (!d || d->n_frames <= 0 || d->height <= 0 || d->width <= 0 || T <= 0 || rate <= 0 || size <= 0) return GAVA_EINVAL;

@@ -21,7 +21,7 @@ EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_text_forward", "gava_similarity_head", "gava_convert_h16", "gava_debug_set_buffer",
            "gava_preprocess_clip", "gava_layernorm_backward", "gava_qgelu_backward", "gava_attention_backward",
            "gava_text_forward_train", "gava_vision_forward_train", "gava_attention_backward_workspace_bytes", "gava_vision_forward_keep", "gava_row_stats",
-           "gava_probe_fc1_enable", "gava_probe_fc1_read", "gava_clip_geometry"]
+           "gava_probe_fc1_enable", "gava_probe_fc1_read", "gava_clip_geometry", "gava_patchify"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 
@@ -103,6 +103,12 @@ class PreprocessArgs(C.Structure):
                 ("first_temporal_view", C.c_int), ("first_spatial_view", C.c_int), ("lut", _fp)]
 
 
+class PatchifyArgs(C.Structure):
+    _fields_ = [("x", _fp), ("clips", _vp), ("clip_lut", _fp),
+                ("B", C.c_int), ("T", C.c_int), ("size", C.c_int), ("patch", C.c_int), ("prec", C.c_int),
+                ("out", _vp), ("ldo", C.c_int64)]
+
+
 class VisionSaved(C.Structure):
     _fields_ = [("e0", _fp), ("x", _fp), ("x1", _fp), ("qkv", _vp), ("pre", _vp), ("sidekv", _vp),
                 ("last_q", _vp), ("last_x1", _fp), ("last_pre", _vp)]
@@ -168,6 +174,8 @@ def load():
     lib.gava_convert_h16.restype = C.c_int
     lib.gava_preprocess_clip.argtypes = [C.POINTER(PreprocessArgs), _vp]
     lib.gava_preprocess_clip.restype = C.c_int
+    lib.gava_patchify.argtypes = [C.POINTER(PatchifyArgs), _vp]
+    lib.gava_patchify.restype = C.c_int
     lib.gava_layernorm_backward.argtypes = [C.POINTER(LayerNormBwdArgs), _vp]
     lib.gava_layernorm_backward.restype = C.c_int
     lib.gava_qgelu_backward.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp]
@@ -304,6 +312,16 @@ def preprocess_clip(frames_u8, out, *, T, rate, size, mean, std, first_temporal_
     a.first_temporal_view, a.first_spatial_view = int(first_temporal_view), int(first_spatial_view)
     a.lut = ptr(lut)
     check(load().gava_preprocess_clip(C.byref(a), stream_ptr()), "gava_preprocess_clip")
+
+
+def patchify(out, *, B, T, size, patch, prec, x=None, clips=None, clip_lut=None):
+    """16-bit patch matrix [B*T*(size/patch)^2, ldo] of the fp32 clips `x` (B,3,T,size,size) or of the uint8 videos behind
+    `clips` (clip_descriptors): the A operand of the patch-embedding GEMM (gemm(A, ..., epilogue=EPI_F32_PATCH))."""
+    a = PatchifyArgs()
+    a.x, a.clips, a.clip_lut = ptr(x), ptr(clips), ptr(clip_lut)
+    a.B, a.T, a.size, a.patch, a.prec = B, T, size, patch, prec
+    a.out, a.ldo = ptr(out), out.stride(0)
+    check(load().gava_patchify(C.byref(a), stream_ptr()), "gava_patchify")
 
 
 # ---- backward ops (SURVEY 8f row 1) ------------------------------------------------------------

@@ -376,6 +376,24 @@ typedef struct {
 } gava_preprocess_args;
 int gava_preprocess_clip(const gava_preprocess_args* a, gava_stream_t stream);
 
+/* The unfold half of ImagePatchEmbed2D (VitaCLIP_vision_encoder_utils.py:31-53: Conv2d(3, D, P, stride P) == patches x
+ * W^T) as one HBM-bound pass: the 16-bit patch matrix the patch-embedding GEMM (gava_gemm, EPI_F32_PATCH with A given)
+ * then reads by LDS-DMA like any other operand.
+ *   out[(b*T + t) * n_patches + py*g + px][c*P*P + ky*P + kx] = h16( in(b, c, t, py*P + ky, px*P + kx) ),  g = size / P,
+ * columns [3*P*P, ldo) are zeroed (K is padded to a multiple of 64 for ViT-L/14).  The input is either
+ *   x      fp32 [B][3][T][size][size], the tensor VitaCLIP.forward takes (VitaCLIP_model.py:241), or
+ *   clips  decoded uint8 videos: device array of B descriptors (gava_clip_desc) + clip_lut fp32 [3][256], evaluated with
+ *          the arithmetic of gava_preprocess_clip (video_dataset/dataset.py:117-139) - the same bits as preprocessing to
+ *          fp32 first, a quarter of the HBM traffic and no fp32 clip in memory.
+ * Rounding to 16 bits is the one the GEMM's own fp32 loader applies (round to nearest even), so the product is unchanged. */
+typedef struct {
+  const float* x;
+  const gava_clip_desc* clips; const float* clip_lut;
+  int B, T, size, patch, prec;
+  void* out; int64_t ldo;             /* ldo >= 3*patch*patch, multiple of 8; out 16-byte aligned */
+} gava_patchify_args;
+int gava_patchify(const gava_patchify_args* a, gava_stream_t stream);
+
 /* fp32 -> h16 conversion of a contiguous array (weight packing at load time). */
 int gava_convert_h16(const float* in, void* out, size_t n, int prec, gava_stream_t stream);
 

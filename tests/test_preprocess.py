@@ -139,6 +139,20 @@ def test_patch_embedding_reads_uint8_frames(size, patch, T, rate, shapes):
         outs.append(X)
     assert torch.equal(outs[0], outs[1])
     assert float(outs[0].abs().max()) > 0.1
+    # the form the forward uses: 16-bit patch matrix first (gava_patchify), then the GEMM with an ordinary A operand
+    ref = x.view(B, 3, T, g, patch, g, patch).permute(0, 2, 3, 5, 1, 4, 6).reshape(B * T * n, K).half()   # unfold, RN to fp16
+    for kw in (dict(x=x), dict(clips=desc, clip_lut=pre.lut(d))):
+        A = torch.full((B * T * n, Kp), 7.0, device=d, dtype=torch.float16)
+        hip.patchify(A, B=B, T=T, size=size, patch=patch, prec=hip.PREC_F16, **kw)
+        assert torch.equal(A[:, :K], ref) and not A[:, K:].any()
+        X = torch.zeros(B * T * (n + 1), D, device=d)
+        hip.gemm(A, W16, bias, X, epilogue=hip.EPI_F32_PATCH, prec=hip.PREC_F16, pos=pos, time=tim, n_patches=n, T=T, M=B * T * n)
+        assert torch.equal(X, outs[0])
+    with pytest.raises(hip.GavaError):
+        hip.patchify(A, B=B, T=T, size=size, patch=patch, prec=hip.PREC_F16)                      # no source
+    with pytest.raises(hip.GavaError):
+        hip.patchify(torch.empty(B * T * n, K - 8, device=d, dtype=torch.float16), B=B, T=T, size=size, patch=patch,
+                     prec=hip.PREC_F16, x=x)                                                      # rows too short for 3 P P
 
 
 @pytest.mark.gpu

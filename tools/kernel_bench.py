@@ -99,6 +99,27 @@ elif a.which == "patchu8":   # the patch embedding reading decoded uint8 videos 
     fn = lambda: hip.gemm(None, W, b, O, epilogue=hip.EPI_F32_PATCH, prec=prec, pos=pos, time=tim, n_patches=n, T=T,
                           M=BT * n, frame_size=224, patch=16, clips=desc, clip_lut=lut)
     fl = 2.0 * BT * n * D * Kp
+elif a.which in ("patchify", "patchifyu8", "patchA"):   # the two-pass patch embedding: patch matrix, then an ordinary GEMM
+    n, Kp = 196, 768
+    W, b, pos, tim = rn(D, Kp, scale=Kp ** -0.5), rn(D, dtype=torch.float32), rn(n + 1, D, dtype=torch.float32), rn(T, D, dtype=torch.float32)
+    O = torch.zeros(BT * (n + 1), D, device=d)
+    A = torch.empty(BT * n, Kp, dtype=dt, device=d)
+    if a.which == "patchifyu8":
+        from gava_clip_amd.preprocess import ClipPreprocessor
+        pre = ClipPreprocessor(num_frames=T, sampling_rate=2, spatial_size=224)
+        vids = [torch.randint(0, 256, (32, 360, 640, 3), dtype=torch.uint8, device=d, generator=g) for _ in range(a.B)]
+        desc, keep = hip.clip_descriptors(vids, T=T, rate=2, size=224)
+        lut = pre.lut(d)
+        fn = lambda: hip.patchify(A, B=a.B, T=T, size=224, patch=16, prec=prec, clips=desc, clip_lut=lut)
+        fl = 0.0
+    else:
+        x = torch.randn(a.B, 3, T, 224, 224, device=d, generator=g)
+        hip.patchify(A, B=a.B, T=T, size=224, patch=16, prec=prec, x=x)
+        if a.which == "patchify":
+            fn = lambda: hip.patchify(A, B=a.B, T=T, size=224, patch=16, prec=prec, x=x); fl = 0.0
+        else:
+            fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32_PATCH, prec=prec, pos=pos, time=tim, n_patches=n, T=T, M=BT * n)
+            fl = 2.0 * BT * n * D * Kp
 elif a.which == "attn":
     QKV, side, O = rn(R, 3 * D), rn(G + 2 * BT, 2 * D), torch.empty(R, D, dtype=dt, device=d)
     fn = lambda: hip.attention(QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, batch=BT, heads=H, n_q=n1, n_kmain=n1,
