@@ -17,7 +17,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "gemm" in k or "attention_kernel" in k or "layernorm_kernel" in k:
+        if "gemm" in k or "attention_" in k or "layernorm_kernel" in k or "patchify" in k:
             agg[k[:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():
     print(k)
