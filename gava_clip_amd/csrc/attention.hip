@@ -82,54 +82,6 @@ __device__ __forceinline__ void stage_kv(const AttnParams& p, int n, int h, char
   }
 }
 
-// The same transfer for a kernel that stages many problems: everything that does not depend on the problem is worked out
-// once per thread (measured in the persistent kernel: recomputing the row -> source map, with its integer division and
-// 64-bit multiplies, for every problem took 2500-4000 cycles of a 12000-cycle problem).  Per 16-byte piece a 32-bit
-// element offset and a 2-bit source type; per problem four wave-uniform base pointers per matrix (scalar unit).
-//   type 0: main row (n n_kmain + row) of k/v     1: global prompt row of side_k/v
-//   type 2: local prompt row, + (n / T) T rows    3: summary row, + n rows
-template <int KP, int NTH>
-struct StagePlan {
-  static constexpr int NIT = (KP * 8 + NTH - 1) / NTH;
-  int coff[NIT];
-  unsigned types;
-};
-template <int KP, int NTH>
-__device__ __forceinline__ StagePlan<KP, NTH> make_stage_plan(const AttnParams& p, int tid) {
-  StagePlan<KP, NTH> pl;
-  pl.types = 0;
-#pragma unroll
-  for (int it = 0; it < pl.NIT; ++it) {
-    const int id = tid + it * NTH;
-    const int row = id >> 3, chunk = (id & 7) ^ (row & 6);
-    const int rowc = row < p.n_keys ? row : 0;
-    const int sidx = rowc - p.n_kmain;
-    const int typ = sidx < 0 ? 0 : sidx < p.n_g ? 1 : sidx < p.n_g + p.T ? 2 : 3;
-    pl.coff[it] = (typ == 0 ? rowc * (int)p.ld : typ == 3 ? (p.n_g + p.batch) * (int)p.lds : sidx * (int)p.lds) + chunk * 8;
-    pl.types |= (unsigned)typ << (2 * it);
-  }
-  return pl;
-}
-template <int KP, int NTH>
-__device__ __forceinline__ void issue_stage_plan(const StagePlan<KP, NTH>& pl, const AttnParams& p, int n, int h,
-                                                 char* Ks, char* Vs, int tid, int wave) {
-  const long o0 = (long)n * p.n_kmain * p.ld + h * 64, o1 = h * 64, o2 = (long)(n / p.T) * p.T * p.lds + h * 64,
-             o3 = (long)n * p.lds + h * 64;
-  const unsigned short* kb[4] = {p.k + o0, p.sk + o1, p.sk + o2, p.sk + o3};
-  const unsigned short* vb[4] = {p.v + o0, p.sv + o1, p.sv + o2, p.sv + o3};
-#pragma unroll
-  for (int it = 0; it < pl.NIT; ++it) {
-    if (tid + it * NTH < KP * 8) {                                     // wave-uniform: KP * 8 is a multiple of 64
-      const unsigned typ = (pl.types >> (2 * it)) & 3;
-      const unsigned short* ksrc = (typ == 0 ? kb[0] : typ == 1 ? kb[1] : typ == 2 ? kb[2] : kb[3]) + pl.coff[it];
-      const unsigned short* vsrc = (typ == 0 ? vb[0] : typ == 1 ? vb[1] : typ == 2 ? vb[2] : vb[3]) + pl.coff[it];
-      const int dst = (wave * 64 + it * NTH) * 16;
-      dma16(ksrc, lds_addr(Ks) + dst);
-      dma16(vsrc, lds_addr(Vs) + dst);
-    }
-  }
-}
-
 // One wave stages a whole problem (the persistent kernel's loader wave): 1 KiB pieces of 8 rows each.  Pieces that lie
 // entirely in the main rows advance two pointers by 8 rows; the few pieces with prompt/summary/padding rows take the
 // general row -> source map of stage_kv.
@@ -571,24 +523,18 @@ __global__ __launch_bounds__(512, 1) void attention_persist_kernel(const AttnPar
   int prob = blockIdx.x;
   if (prob >= n_prob) return;
   int n = prob / p.heads, h = prob - n * p.heads;
-  // problem-independent parts of every address this thread forms, once
-  const StagePlan<KP, NWV * 64> plan = make_stage_plan<KP, NWV * 64>(p, tid);
+  // problem-independent parts of the Q / O addresses this thread forms, once
   const int qia = wave * 32 + fr, qib = qia + 16;
   const int qoa = (qia < p.n_q ? qia : p.n_q - 1) * (int)p.ldq + 8 * fg;   // a tile beyond n_q computes garbage, stores nothing
   const int qob = (qib < p.n_q ? qib : p.n_q - 1) * (int)p.ldq + 8 * fg;
   const int ooa = qia * (int)p.ldo + 4 * fg, oob = qib * (int)p.ldo + 4 * fg;
   const bool valid_a = qia < p.n_q, valid_b = qib < p.n_q;
   auto q_base = [&](int n_, int h_) { return p.q + ((long)n_ * p.qbr * p.ldq + h_ * 64); };
-  // With a wave to spare (7 pairs at 197 queries) that wave alone issues the next problem's K/V: 56 LDS-DMA instructions
-  // take ~3000 cycles to get accepted by the memory pipeline (measured), which the computing waves would otherwise all
-  // spend at the top of every problem before their first MFMA.
-  const bool use_loader = (n_qt + 1) / 2 < NWV;
+  // The last wave never has a query-tile pair here (n_q <= n_keys <= 224: at most 7 pairs) and alone issues the next
+  // problem's K/V: 56 LDS-DMA instructions take ~3000 cycles to get accepted by the memory pipeline (measured), which the
+  // computing waves would otherwise all spend at the top of every problem before their first MFMA.
   auto stage = [&](int n_, int h_, char* kd, char* vd) {
-    if (use_loader) {
-      if (wave == NWV - 1) stage_kv_one_wave<KP>(p, n_, h_, kd, vd, lane);
-    } else {
-      issue_stage_plan(plan, p, n_, h_, kd, vd, tid, wave);
-    }
+    if (wave == NWV - 1) stage_kv_one_wave<KP>(p, n_, h_, kd, vd, lane);
   };
   s16x8_t q0 = {0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, qb0 = q0, qb1 = q0;
   stage(n, h, Ks, Vs);
@@ -684,7 +630,7 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
 #else
   const bool dbg_ok = !p.dbg;
 #endif
-  if (persist_ok && pair && tiles == 14 && p.n_q <= 256 && dbg_ok && n_prob >= 4 * n_cu) {
+  if (persist_ok && pair && tiles == 14 && p.n_q <= 14 * 16 && dbg_ok && n_prob >= 4 * n_cu) {
     hipLaunchKernelGGL((attention_persist_kernel<P, 14, 13>), dim3(n_cu), dim3(512), 0, s, p, n_prob);
     GAVA_CHECK_LAUNCH();
     return GAVA_OK;

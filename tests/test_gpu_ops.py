@@ -135,7 +135,8 @@ def attn_ref(q, k, v, causal):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("batch,heads,L,causal", [(3, 8, 77, True), (5, 2, 8, False), (2, 12, 16, False),
-                                                  (4, 2, 197, False), (1, 16, 257, False)])
+                                                  (4, 2, 197, False), (1, 16, 257, False),
+                                                  (90, 12, 215, False)])   # persistent kernel, no prompt rows, 14 full query tiles
 def test_attention_plain_and_causal(prec, batch, heads, L, causal):
     d = dev()
     dt = hip.h16_dtype(prec)
