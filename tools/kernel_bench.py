@@ -15,6 +15,7 @@ ap.add_argument("which")
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--B", type=int, default=64)
 ap.add_argument("--prec", default="fp16")
+ap.add_argument("--rows", type=int, default=0, help="override the row count R of the GEMM / LayerNorm cases (tile-quantisation probes)")
 ap.add_argument("--cfg", default="VIT_B16_T8", help="config name in gava_clip_amd.config (VIT_L14_T32 for the 320-key attention class)")
 a = ap.parse_args()
 cfg = getattr(_config, a.cfg)
@@ -24,6 +25,8 @@ d = torch.device("cuda")
 D, F, H, T, G, n1 = cfg.feature_dim, cfg.mlp_dim, cfg.num_heads, cfg.num_frames, cfg.num_global_prompts, cfg.tokens_main
 BT = a.B * T
 R = BT * n1
+if a.rows:
+    R = a.rows
 g = torch.Generator(device="cuda").manual_seed(1)
 rn = lambda *s, scale=1.0, dtype=dt: (torch.randn(*s, device=d, generator=g) * scale).to(dtype)
 if a.which == "fc1":
