@@ -136,7 +136,9 @@ def attn_ref(q, k, v, causal):
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("batch,heads,L,causal", [(3, 8, 77, True), (5, 2, 8, False), (2, 12, 16, False),
                                                   (4, 2, 197, False), (1, 16, 257, False),
-                                                  (90, 12, 215, False)])   # persistent kernel, no prompt rows, 14 full query tiles
+                                                  (90, 12, 215, False),    # persistent kernel, no prompt rows, 14 query tiles
+                                                  (86, 12, 224, False),    # ... its largest problem: 224 keys, no masked key at all
+                                                  (3, 4, 209, False)])     # smallest key count of the 14-tile class (one key in the last tile)
 def test_attention_plain_and_causal(prec, batch, heads, L, causal):
     d = dev()
     dt = hip.h16_dtype(prec)
