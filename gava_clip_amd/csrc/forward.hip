@@ -451,7 +451,23 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
     TRY(gava_gemm(&a, stream));
   }
   TRY(gava::cls_embed(sv->e0, m->cls_token, m->pos_embed, m->time_embed, BT, m->T_in, D, fs, s));
-  TRY(ln(sv->e0, D, nullptr, m->lnpre_g, m->lnpre_b, nullptr, 0, sv->x, D, R, D, pr, stream));
+  // LayerNorm folding as in the inference driver (norm1 / norm2 of the vision blocks are frozen, VitaCLIP_model.py:230-239, so
+  // the folded weight copies stay valid while training; the backward recomputes the statistics from the kept fp32 stream and
+  // never needs the normalised activations).  GAVA_TRAIN_FOLD=0: separate LayerNorm launches (A/B).
+  static const bool fold_env = !(getenv("GAVA_TRAIN_FOLD") && getenv("GAVA_TRAIN_FOLD")[0] == '0');
+  static const bool fused_env = !(getenv("GAVA_FUSED_STATS") && getenv("GAVA_FUSED_STATS")[0] == '0');
+  const bool can_fold = fold_env && D % 64 == 0 && m->layers >= 1 && m->layer[0].w_fc1_fold && m->layer[0].w_qkv_fold;
+  const bool fused = fused_env && R >= 8192 && D % 256 == 0 && D <= 1024 && D >= 256;
+  Fold produce; produce.x16 = w.Xn; produce.ld_x16 = D; produce.rowsum = w.RSUM; produce.reduced = fused ? 1 : 0;
+  auto consume = [&](const float* s_, const float* t_) {
+    Fold c; c.s = s_; c.t = t_;
+    if (fused) c.partials = w.RSUM; else c.stats = w.STATS;
+    return c;
+  };
+  // ln_pre, and with folding norm1 of block 0 in the same row pass
+  if (can_fold) TRY(ln(sv->e0, D, nullptr, m->lnpre_g, m->lnpre_b, w.Xn, D, sv->x, D, R, D, pr, stream, 0, m->layer[0].ln1_g, m->layer[0].ln1_b));
+  else TRY(ln(sv->e0, D, nullptr, m->lnpre_g, m->lnpre_b, nullptr, 0, sv->x, D, R, D, pr, stream));
+  bool folded_in = false;   // Xn / RSUM already hold this block's un-normalised input and its row-sum partials
   for (int i = 0; i < m->layers; ++i) {
     const gava_vision_layer& L = m->layer[i];
     const unsigned short* wqkv = (const unsigned short*)L.w_qkv;
@@ -482,16 +498,28 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
     TRY(gava::side_ln(L.global_prompts, L.local_prompts, w.CP, w.SUMM, L.ln1_g, L.ln1_b, w.SIDEn, G, Tm, BT, D, pr, (hipStream_t)ss));
     TRY(gemm(w.SIDEn, D, wqkv + (long)D * D, D, L.b_qkv + D, SKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, ss));
     if (two && hipEventRecord(g_side.join[i], g_side.s) != hipSuccess) return GAVA_ELAUNCH;
-    const int resv = two ? side_cus(false) : 0;
-    TRY(ln(Xin, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
-    if (i + 1 == m->layers && sv->last_q && sv->last_x1 && sv->last_pre) {
+    const bool last_cls = i + 1 == m->layers && sv->last_q && sv->last_x1 && sv->last_pre;
+    const bool fold1 = folded_in;                                               // set by the previous block's fc2
+    const bool fold2 = can_fold && !last_cls && L.w_fc1_fold;                   // out_proj produces, fc1 consumes
+    const bool fold1_next = can_fold && i + 1 < m->layers && m->layer[i + 1].w_qkv_fold;   // fc2 produces for the next qkv / K,V GEMM
+    const int resv = two ? side_cus(fold1) : 0;
+    if (!fold1 && !(i == 0 && can_fold)) TRY(ln(Xin, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
+    if (last_cls) {
       // Last block, as in the inference driver: keys/values for every row, queries / out_proj / MLP for the B*T CLS
       // rows only (VitaCLIP_vision_encoder.py:126 reads x[:,0]).  Kept: K/V in the QKV slot, the CLS queries, the CLS
       // rows of the stream after attention, the CLS pre-activations.
       unsigned short* QC = (unsigned short*)sv->last_q;
       unsigned short* PREC = (unsigned short*)sv->last_pre;
-      TRY(gemm(w.Xn, D, wqkv + (long)D * D, D, L.b_qkv + D, QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, nullptr, resv));
-      TRY(gemm(w.Xn, fs, L.w_qkv, D, L.b_qkv, QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+      if (fold1) {   // norm1 folded into the K/V GEMM; the B*T CLS queries get a LayerNorm of their own
+        Fold c = consume(L.qkv_fold_s + D, L.qkv_fold_t + D);
+        TRY(gemm(w.Xn, D, (const unsigned short*)L.w_qkv_fold + (long)D * D, D, nullptr, QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream,
+                 nullptr, 0, 0, 1.f, 0, nullptr, &c, resv));
+        TRY(ln(Xin, fs, nullptr, L.ln1_g, L.ln1_b, w.XNC, D, nullptr, 0, BT, D, pr, stream));
+        TRY(gemm(w.XNC, D, L.w_qkv, D, L.b_qkv, QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+      } else {
+        TRY(gemm(w.Xn, D, wqkv + (long)D * D, D, L.b_qkv + D, QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, nullptr, resv));
+        TRY(gemm(w.Xn, fs, L.w_qkv, D, L.b_qkv, QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+      }
       if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
       {
         gava_attention_args a{};
@@ -509,7 +537,12 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
       TRY(gemm(w.HIDC, F, L.w_fc2, F, L.b_fc2, Xout, fs, BT, D, F, GAVA_EPI_F32, pr, stream, sv->last_x1, D));
       continue;
     }
-    TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, nullptr, resv));
+    if (fold1) {
+      Fold c = consume(L.qkv_fold_s, L.qkv_fold_t);
+      TRY(gemm(w.Xn, D, L.w_qkv_fold, D, nullptr, QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, &c, resv));
+    } else {
+      TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, nullptr, resv));
+    }
     if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
     {
       gava_attention_args a{};
@@ -520,10 +553,23 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
       a.n_g = G; a.T = Tm; a.has_summary = 1; a.prec = pr;
       TRY(gava_attention(&a, stream));
     }
-    TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, X1, D, R, D, D, GAVA_EPI_F32, pr, stream, Xin, D));
-    TRY(ln(X1, D, nullptr, L.ln2_g, L.ln2_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
-    TRY(gemm(w.Xn, D, L.w_fc1, D, L.b_fc1, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, 0, PRE));
-    TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, Xout, D, R, D, F, GAVA_EPI_F32, pr, stream, X1, D));
+    if (fold2) {
+      TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, X1, D, R, D, D, GAVA_EPI_F32, pr, stream, Xin, D, 0, 1.f, 0, nullptr, &produce));
+      if (!fused) TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
+      Fold c = consume(L.fc1_fold_s, L.fc1_fold_t);
+      TRY(gemm(w.Xn, D, L.w_fc1_fold, D, nullptr, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, 0, PRE, &c));
+    } else {
+      TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, X1, D, R, D, D, GAVA_EPI_F32, pr, stream, Xin, D));
+      TRY(ln(X1, D, nullptr, L.ln2_g, L.ln2_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
+      TRY(gemm(w.Xn, D, L.w_fc1, D, L.b_fc1, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, 0, PRE));
+    }
+    if (fold1_next) {
+      TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, Xout, D, R, D, F, GAVA_EPI_F32, pr, stream, X1, D, 0, 1.f, 0, nullptr, &produce));
+      if (!fused) TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
+    } else {
+      TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, Xout, D, R, D, F, GAVA_EPI_F32, pr, stream, X1, D));
+    }
+    folded_in = fold1_next;
   }
   const float* Xf = sv->x + (size_t)m->layers * RD;
   TRY(ln(Xf, fs, nullptr, m->lnpost_g, m->lnpost_b, w.CLSPOST, 3 * D, nullptr, 0, BT, D, pr, stream, 1));
