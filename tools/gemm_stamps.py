@@ -53,4 +53,5 @@ for grp, name in ((slice(0, 4), "group0 (waves 0-3)"), (slice(4, 8), "group1 (wa
     x = d[:, grp].reshape(-1, 8)
     G = x[:, 5].mean()
     tot = x[:, :5].sum(1).mean()
-    print(f"{which} {name}: stages/wave {G:.0f}; per stage cycles: vmcnt-wait {x[:,0].mean()/G:.0f}  barrier {x[:,1].mean()/G:.0f}  body {x[:,2].mean()/G:.0f}  epilogue {x[:,4].mean()/G:.0f}  total {tot/G:.0f}")
+    print(f"{which} {name}: stages/wave {G:.0f}; per stage cycles: vmcnt-wait {x[:,0].mean()/G:.0f}  barrier {x[:,1].mean()/G:.0f}  body {x[:,2].mean()/G:.0f}  epilogue {x[:,4].mean()/G:.0f}  total {tot/G:.0f}"
+          + (f"  [epilogue: bias wait {x[:,6].mean()/G:.0f}, row groups {x[:,7].mean()/G:.0f}]" if x[:,6].sum() > 0 else ""))
