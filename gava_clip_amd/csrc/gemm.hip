@@ -442,7 +442,7 @@ void gemm256_kernel(const GemmParams p) {
   // (mean, rstd) pairs of ITS 128 rows (1 KiB) and s_n of ITS 64 columns (256 B) by LDS-DMA into a private, tile-parity
   // indexed block behind the ring: no barrier is needed before it reads them back, only its own vmcnt.
   constexpr bool CAN_FOLD = FOLD;
-  constexpr int FOLD_WAVE = 1280, FOLD_BYTES = NW * FOLD_WAVE;
+  constexpr int FOLD_WAVE = 1536, FOLD_BYTES = NW * FOLD_WAVE;   // per wave: 1 KiB of row statistics / partials, 256 B of s_n, 256 B of t_n
   // producers of the folding (EPI_F32 + x16_out): the 16-bit copy of a row group goes through a wave-private LDS block
   // (16 rows x 128 B, 16-byte chunks XOR-swizzled by (row >> 1) & 7: conflict-free for the 8-byte writes and the 16-byte
   // reads) so that it leaves as 128 contiguous bytes per row - 2 store instructions touching 16 lines instead of 4
@@ -526,6 +526,11 @@ void gemm256_kernel(const GemmParams p) {
       const char* ss = reinterpret_cast<const char*>(p.fs) + (size_t)(nn0 + wc * 64) * 4;
       __builtin_amdgcn_global_load_lds(GLB_PTR(st + l16), LDS_PTR(void, fb), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(GLB_PTR(ss + l4), LDS_PTR(void, fb + 1024), 4, 0, 0);
+      // t_n (the folded bias) of the same 64 columns: read back at the top of the epilogue instead of a global load there,
+      // whose wait (vmcnt(0): the operand prefetch of the next tile is in flight) cost the older wave group 230 cycles per
+      // stage in the qkv GEMM (tools/gemm_stamps.py qkvpart)
+      const char* tt = reinterpret_cast<const char*>(p.ft) + (size_t)(nn0 + wc * 64) * 4;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(tt + l4), LDS_PTR(void, fb + 1280), 4, 0, 0);
     }
   };
   // fragment read offsets.  A rows: wr*128 + i*16 + fr, swizzle (row>>1)&7 = fr>>1.
@@ -732,9 +737,24 @@ void gemm256_kernel(const GemmParams p) {
     //      n = n0 + wc*64 + 16*fg + 4*jj + r
     const int nb0 = n0 + wc * 64 + CF * fg;
     float4 bj[4];
+    if (CAN_FOLD) {   // t_n from this tile's fold block (LDS, by hand: see fold_init)
+      unsigned a_t = (lane >> 4) * 64u;
+      asm volatile("" : "+v"(a_t));
+      a_t += (unsigned)(size_t)LDS_PTR(char, smem) + 2 * STAGE + (j & 1) * FOLD_BYTES + wave * FOLD_WAVE;
+      f32x4_t tj[4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-      bj[jj] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb0 + CJ * jj) : make_float4(0, 0, 0, 0);
+      for (int jj = 0; jj < 4; ++jj) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tj[jj]) : "v"(a_t), "n"(1280 + jj * 16));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        asm volatile("" : "+v"(tj[jj]));
+        bj[jj] = make_float4(tj[jj][0], tj[jj][1], tj[jj][2], tj[jj][3]);
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        bj[jj] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb0 + CJ * jj) : make_float4(0, 0, 0, 0);
+    }
     // One explicit use on the common path: the compiler waits for the bias HERE, once.  Without it every row
     // below (a basic block of its own behind `m < M`) re-waits with vmcnt(0), i.e. for the previous row's stores.
 #pragma unroll

@@ -31,6 +31,16 @@ elif which in ("fc1fold", "qkvfold"):   # consumers with LayerNorm folded in
         fn = lambda: hip.gemm(A, W, None, O, epilogue=hip.EPI_H16_QGELU, prec=0, fold_stats=st, fold_s=fs_, fold_t=ft_)
     else:
         fn = lambda: hip.gemm(A, W, None, O, epilogue=hip.EPI_H16, prec=0, scale_cols=D, scale=0.125, fold_stats=st, fold_s=fs_, fold_t=ft_)
+elif which in ("fc1part", "qkvpart"):   # consumers in the product's mode: (mean, rstd) derived from the producers' partials
+    N = F if which == "fc1part" else 3 * D
+    Rp = (R + 255) // 256 * 256
+    A, W, O = rn(R, D), rn(N, D, scale=D ** -0.5), torch.empty(R, N, dtype=torch.float16, device="cuda")
+    part = torch.rand(Rp + 32, 4, 2, dtype=torch.float32, device="cuda", generator=g) * 40 + 200
+    fs_, ft_ = W.float().sum(1).contiguous(), rn(N, dtype=torch.float32)
+    if which == "fc1part":
+        fn = lambda: hip.gemm(A, W, None, O, epilogue=hip.EPI_H16_QGELU, prec=0, fold_partials=part, fold_s=fs_, fold_t=ft_)
+    else:
+        fn = lambda: hip.gemm(A, W, None, O, epilogue=hip.EPI_H16, prec=0, scale_cols=D, scale=0.125, fold_partials=part, fold_s=fs_, fold_t=ft_)
 elif which in ("outfold", "fc2fold", "out"):
     K = F if which == "fc2fold" else D
     Rp = (R + 255) // 256 * 256
