@@ -650,7 +650,7 @@ void gemm256_kernel(const GemmParams p) {
 #else
   constexpr bool stamp = false;
 #endif
-  unsigned long long ts = 0, tW = 0, tB = 0, tC = 0, tE = 0;
+  unsigned long long ts = 0, tW = 0, tB = 0, tC = 0, tE = 0, tE1 = 0, tE2 = 0, te = 0;   // tE1 / tE2: epilogue until the bias is there / its row groups
   bool in_epi = false;
   if (stamp) ts = clock64();
   // Static priority for the second-dispatched half: at equal priority waves 4-7 lose every issue arbitration to
@@ -759,6 +759,7 @@ void gemm256_kernel(const GemmParams p) {
     // below (a basic block of its own behind `m < M`) re-waits with vmcnt(0), i.e. for the previous row's stores.
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) asm volatile("" ::"v"(bj[jj].x), "v"(bj[jj].y), "v"(bj[jj].z), "v"(bj[jj].w));
+    if (stamp) { te = clock64(); tE1 += te - ts; }
     const bool full = m0 + BM <= p.M;
     // folded LayerNorm: out = rstd_m * acc + t_n (acc already holds x.W' - mean_m * s_n; t_n came in as the bias)
     // rstd of row i+1 is fetched (LDS, by hand: see fold_init) while row i is processed: two registers, not eight
@@ -901,6 +902,7 @@ void gemm256_kernel(const GemmParams p) {
         asm volatile("v_mov_b32 %0, %1" : "=v"(r_cur) : "v"(r_next));
       }
     }
+    if (stamp) { const unsigned long long t = clock64(); tE2 += t - te; }
     if (CAN_FOLD && j + 1 < my_tiles) {
       // the next tile's fold block was issued before this epilogue's stores: it has landed once at most those are in flight
       // (partials mode: it landed, and was reduced, two stages ago)
@@ -925,7 +927,7 @@ void gemm256_kernel(const GemmParams p) {
     const unsigned long long t = clock64();
     tE += t - ts;
     unsigned long long* d = p.dbg + (size_t)(blockIdx.x * 8 + wave) * 8;
-    d[0] = tW; d[1] = tB; d[2] = tC; d[3] = 0; d[4] = tE; d[5] = (unsigned long long)G;
+    d[0] = tW; d[1] = tB; d[2] = tC; d[3] = 0; d[4] = tE; d[5] = (unsigned long long)G; d[6] = tE1; d[7] = tE2;
   }
 }
 
