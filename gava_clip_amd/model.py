@@ -573,6 +573,9 @@ class _HipHost:
             B, Cc, T, Hh, Ww = x.shape
             assert Cc == 3 and Hh == sh["size"] and Ww == sh["size"], "input must be (B,3,T,size,size)"
             x = x.detach().float().contiguous()
+        if B == 0:   # an empty batch is not an error upstream (every op of the reference accepts zero clips): empty features
+            self.last["summary"] = torch.zeros(0, sh["D"], device=x.device)
+            return torch.zeros(0, sh["E"], device=x.device), self.last["summary"]
         te = self.visual.time_embed.detach().float()
         if T != te.size(0):  # VitaCLIP_vision_encoder.py:91-95
             te = F.interpolate(te.unsqueeze(0).transpose(1, 2), size=(T), mode='nearest').transpose(1, 2).squeeze(0)
@@ -1035,6 +1038,9 @@ class VitaCLIP(nn.Module, _HipHost):
                 n_cls, n_kv = Cn, 1      # per-description logits (VitaCLIP_model.py:265-276): every prompt is its own "class"
             else:
                 n_cls = Cn // n_kv
+            empty = Bg == 0          # no clips (upstream returns (0, C) logits and still refreshes text_features): one dummy row
+            if empty:
+                video, Bg = torch.zeros(1, sh["E"], dtype=torch.float32, device=x.device), 1
             logits = torch.empty(Bg, n_cls, dtype=torch.float32, device=x.device)
             tfeat = torch.empty(n_cls, sh["E"], dtype=torch.float32, device=x.device)
             vnorm = torch.empty(Bg, sh["E"], dtype=torch.float32, device=x.device)
@@ -1043,6 +1049,8 @@ class VitaCLIP(nn.Module, _HipHost):
             hip.check(lib.gava_similarity_head(hip.ptr(video), hip.ptr(text), hip.ptr(ls), hip.ptr(lb), Bg, n_cls, n_kv,
                                                sh["E"], hip.ptr(logits), hip.ptr(tfeat), hip.ptr(vnorm), hip.stream_ptr(x.device)),
                       "gava_similarity_head")
+            if empty:
+                logits, vnorm = logits[:0], vnorm[:0]
             self.last.update(video_features=vnorm, summary=summary)
             if desc_wise and self.use_text_prompt_learning:
                 self.text_features = tfeat            # upstream leaves the last class's features here; not relied upon

@@ -126,6 +126,26 @@ def test_desc_wise_and_zero_input():
     assert rel_to_max(full.cpu().numpy(), want) < 1e-3
 
 
+def test_empty_batch_and_single_class(tmp_path):
+    """Edges the reference's torch ops accept: a batch of zero clips gives (0, C) logits (and still refreshes text_features);
+    a class list with a single name gives (B, 1) logits that match the oracle."""
+    m, sd = build(TINY)
+    with torch.no_grad():
+        full, _, _ = m(torch.from_numpy(synth.synth_clip(2, TINY.num_frames, TINY.input_size)).cuda())
+        tf = m.text_features.clone()
+        logits, a, b = m(torch.zeros(0, 3, TINY.num_frames, TINY.input_size, TINY.input_size).cuda())
+    assert tuple(logits.shape) == (0, 3) and a is None and b is None
+    assert torch.equal(m.text_features, tf)
+    one = tmp_path / "one_class.txt"
+    one.write_text("walking\n")
+    m1, sd1 = build(TINY, class_file=str(one), n_cls=1)
+    x = torch.from_numpy(synth.synth_clip(3, TINY.num_frames, TINY.input_size, seed=5))
+    with torch.no_grad():
+        l1, _, _ = m1(x.cuda())
+    want = Oracle(TINY, sd1, torch.cat(m1.tokenized_prompts)).forward(x)["logits"].numpy()
+    assert tuple(l1.shape) == (3, 1) and rel_to_max(l1.cpu().numpy(), want) < 1e-3
+
+
 def test_text_400_classes_matches_oracle():
     """config c3's text side: 400 prompts batched through one text-encoder pass."""
     from helpers import CLASSES_400
