@@ -199,7 +199,12 @@ int check_vision(const gava_vision_model* m) {
 
 }  // namespace
 
-extern "C" int gava_abi_version(void) { return 1; }
+// The ABI version is a hash of include/gava_hip.h, baked in by gava_clip_amd/build.py (-DGAVA_ABI_HASH): a library built from
+// another header than the one its caller mirrors is refused at load time (gava_clip_amd/hip.py load()).
+#ifndef GAVA_ABI_HASH
+#error "build with -DGAVA_ABI_HASH=<first 31 bits of sha256(include/gava_hip.h)> (python -m gava_clip_amd.build does)"
+#endif
+extern "C" int gava_abi_version(void) { return (int)(GAVA_ABI_HASH); }
 
 extern "C" int gava_probe_fc1_enable(int on) {
   Fc1Probe& g_probe = device_ctx().probe;
@@ -267,8 +272,13 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
   // ln_pre, and in the same row pass norm1 of block 0 (both read the same rows: one read of the embedding instead of two)
   static const bool no_prefuse = getenv("GAVA_NO_PREFUSE") != nullptr;     // A/B switches (tools/ab_env.py)
   static const bool no_lastfold = getenv("GAVA_NO_LASTFOLD") != nullptr;
-  // timing diagnostics only (results are WRONG): how much of a kernel's duration the forward gives back when it is removed
+  // timing diagnostics (results are WRONG): how much of a kernel's duration the forward gives back when it is removed.
+  // Compiled in only by experiment builds (tools/ab_build.sh NAME -DGAVA_ENABLE_ABLATE), never into the product library.
+#ifdef GAVA_ENABLE_ABLATE
   static const bool skip_attn = getenv("GAVA_DIAG_SKIP_ATTN") != nullptr, skip_stats = getenv("GAVA_DIAG_SKIP_STATS") != nullptr;
+#else
+  constexpr bool skip_attn = false, skip_stats = false;
+#endif
   const bool pre_fused = m->layers >= 1 && !no_prefuse;
   if (pre_fused) TRY(ln(w.X, D, nullptr, m->lnpre_g, m->lnpre_b, w.Xn, D, w.X, D, R, D, pr, stream, 0, m->layer[0].ln1_g, m->layer[0].ln1_b));
   else TRY(ln(w.X, D, nullptr, m->lnpre_g, m->lnpre_b, nullptr, 0, w.X, D, R, D, pr, stream));

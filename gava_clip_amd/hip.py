@@ -155,6 +155,14 @@ def load():
                         "(the HIP path has no fallback)")
     lib = C.CDLL(LIB_PATH)
     lib.gava_abi_version.restype = C.c_int
+    # the library reports the hash of the header it was compiled against; the ctypes mirrors in this file follow the header
+    # in the tree (tests/test_host_cpu.py compares every struct size with the C compiler's): a stale .so would be called with
+    # shifted structs, so it is refused here
+    from .build import abi_hash
+    have, want = lib.gava_abi_version(), abi_hash()
+    if have != want:
+        raise GavaError(f"{LIB_PATH} was built from another include/gava_hip.h (ABI {have:#x}, header in the tree {want:#x}): "
+                        "rebuild with `python -m gava_clip_amd.build --force`")
     for name, args in (("gava_gemm", [C.POINTER(GemmArgs), _vp]),
                        ("gava_layernorm", [C.POINTER(LayerNormArgs), _vp]),
                        ("gava_attention", [C.POINTER(AttentionArgs), _vp])):

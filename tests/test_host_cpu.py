@@ -21,7 +21,28 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gava_abi_version() == 1
+    from gava_clip_amd.build import abi_hash, needs_build
+    assert lib.gava_abi_version() == abi_hash()
+    assert not needs_build()          # the content hash stored next to the library matches csrc/ + the header
+
+
+def test_a_library_built_from_another_header_is_refused(tmp_path, monkeypatch):
+    """gava_abi_version() is a hash of include/gava_hip.h baked in at build time; hip.load() must refuse a library whose
+    hash differs from the header in the tree (a stale .so would be called with shifted structs)."""
+    import subprocess
+    from gava_clip_amd import build as B, hip
+    stale = str(tmp_path / "libgava_stale.so")
+    # a one-symbol stand-in is enough: load() checks the version before it binds anything else
+    src = tmp_path / "stale.c"
+    src.write_text("int gava_abi_version(void) { return %d; }\n" % ((B.abi_hash() ^ 0x5a5a) & 0x7fffffff))
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(src), "-o", stale])
+    monkeypatch.setattr(hip, "LIB_PATH", stale)
+    monkeypatch.setattr(hip, "_lib", None)
+    with pytest.raises(hip.GavaError, match="another include/gava_hip.h"):
+        hip.load()
+    monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.raises(hip.GavaError, match="missing"):
+        hip.load()
 
 
 def test_ctypes_structs_match_header_sizes():

@@ -5,9 +5,10 @@
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
+abi=$(python -c "from gava_clip_amd.build import abi_hash; print(abi_hash())")
 mkdir -p gava_clip_amd/build/$name
 for f in gemm attention rowops forward preprocess backward attention_bwd; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c gava_clip_amd/csrc/$f.hip -o gava_clip_amd/build/$name/$f.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DGAVA_ABI_HASH=$abi "$@" -c gava_clip_amd/csrc/$f.hip -o gava_clip_amd/build/$name/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gava_clip_amd/libgava_hip_$name.so gava_clip_amd/build/$name/*.o

@@ -81,13 +81,15 @@ def load_synth(model, cfg, n_cls, seed=0, aux=False, kapt=False):
     return sd
 
 
-def run_case(mod, cfg, class_file, B, name, full_trace):
+def run_case(mod, cfg, class_file, B, name, full_trace, wseed=0, xseed=1234, compact=False):
+    """One eval forward of the REFERENCE (evaluation/evaluate.py:263-283).  `compact` keeps only the outputs (logits,
+    scores, features, summary): the round-3 fixtures at other seeds / shapes."""
     from gava_clip_amd.tokenizer import read_class_names
     n_cls = len(read_class_names(class_file))
     model = build_reference(mod, cfg, class_file)
-    load_synth(model, cfg, n_cls)
+    load_synth(model, cfg, n_cls, seed=wseed)
     model.eval()
-    x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size, seed=1234))
+    x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size, seed=xseed))
     blocks_out = []
     hooks = [blk.register_forward_hook(lambda m, i, o: blocks_out.append((o[0].detach(), o[1].detach())))
              for blk in model.visual.blocks]
@@ -111,7 +113,11 @@ def run_case(mod, cfg, class_file, B, name, full_trace):
         summ_last=blocks_out[-1][1].numpy(),
         x_checksum=np.array([float(x.double().sum()), float(x.double().abs().sum())]),
         tokens=torch.cat(model.tokenized_prompts).numpy().astype(np.int32),
+        wseed=np.array(wseed), xseed=np.array(xseed),
     )
+    if compact:
+        for k in ("cls_rows", "patch_row7", "block_fro", "summ_last", "tokens"):
+            del out[k]
     if full_trace:
         for i, b in enumerate(blocks_out):
             out[f"block{i}"] = torch.cat((b[0][:, :1], b[0][:, G + 1:]), 1).numpy()
@@ -312,6 +318,16 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     mod, txt_mod = import_reference()
     C3 = os.path.join(CLASSES, "updrs_3cls_classes.txt")
+    if "--round3" in sys.argv:      # only the fixtures added in round 3: more seeds at c1, one clip at c3 and c5 shapes
+        from gava_clip_amd.config import VIT_B16_T16, VIT_L14_T32
+        for sidx in (1, 2, 3):      # other weights AND other clips than c1_b16.npz (wseed 0, xseed 1234)
+            run_case(mod, VIT_B16_T8, C3, 2, f"c1_b16_s{sidx}", False, wseed=sidx, xseed=1234 + sidx, compact=True)
+        # c3's clip 0 (16 frames, 400 classes: 400 sequential text passes upstream, VitaCLIP_model.py:282-290); the
+        # input is the clip tests/test_gpu_forward.py puts first in its 32-clip batch
+        run_case(mod, VIT_B16_T16, os.path.join(CLASSES, "k400_classes.txt"), 1, "c3_clip0", False, xseed=3, compact=True)
+        # c5's clip 0 (ViT-L/14, 32 frames), likewise
+        run_case(mod, VIT_L14_T32, C3, 1, "c5_clip0", False, xseed=5, compact=True)
+        sys.exit(0)
     if "--round2" in sys.argv:      # only the fixtures added in round 2 (the others are unchanged)
         run_kapt_case(mod, TINY, C3, 2, "tiny_kapt_nodisc", init="cntn_split_uni")
         run_zeroshot_case(mod, TINY, C3, 2, "tiny_zeroshot")
