@@ -84,6 +84,28 @@ def test_c1_vit_b16_vs_golden(golden_dir, prec, tol):
     assert tuple(m.text_features.shape) == (3, 512)
 
 
+@pytest.mark.parametrize("name", ["c1_b16_s1", "c1_b16_s2", "c1_b16_s3"])
+def test_c1_other_seeds_vs_reference_golden(golden_dir, name):
+    """Three more reference runs at c1 shapes (other weights AND other clips; tools/gen_golden.py --round3), judged by the
+    same frozen criteria as c1_b16: norm-wise 1e-3 and the mixed element-wise bound of tests/helpers.py."""
+    from helpers import golden_case
+    cfg, class_file, n_cls, B, wseed, xseed = golden_case(name)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = VitaCLIP(**model_kwargs(cfg, class_file), operand_dtype="fp16")
+    m.load_state_dict(synth_torch_state(cfg, n_cls, wseed), strict=True)
+    m = m.cuda().eval()
+    x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size, seed=xseed)).cuda()
+    with torch.no_grad():
+        lg = m(x)[0].cpu().numpy()
+    e_rel, viol, e_el = rel_to_max(lg, g["logits"]), mixed_violation(lg, g["logits"]), elementwise_rel(lg, g["logits"])
+    print(f"\n[{name}] logits {g['logits'].round(3).tolist()} rel-to-max {e_rel:.3e} mixed {viol:.3f} elementwise {e_el:.3e}; "
+          f"video {rel_to_max(m.last['video_features'].cpu().numpy(), g['video_features']):.3e} "
+          f"text {rel_to_max(m.text_features.cpu().numpy(), g['text_features']):.3e}")
+    assert e_rel < 1e-3
+    assert viol <= 1.0
+    assert np.array_equal(lg.argmax(-1), g["logits"].argmax(-1))
+
+
 def test_forward_is_deterministic_and_batch_invariant():
     """Clips are independent: a clip's logits must not depend on its batch mates, and
     two runs are bit-identical (no atomics anywhere on the path)."""
@@ -316,9 +338,10 @@ def test_c2_full_size_batch_is_anchored_to_the_golden_and_deterministic(golden_d
     assert e_small < 5e-4
 
 
-def test_c3_full_size_batch_is_anchored_to_the_oracle_and_deterministic():
-    """BASELINE config c3 (32 clips, 16 frames, 400 classes, full depth): the logits of clip 0 meet the oracle's for that
-    clip alone (clips are independent), two runs are bit-identical."""
+def test_c3_full_size_batch_is_anchored_to_the_reference_and_deterministic(golden_dir):
+    """BASELINE config c3 (32 clips, 16 frames, 400 classes, full depth): the logits of clip 0 meet the REFERENCE's for that
+    clip alone (tests/golden/c3_clip0.npz, a reference run of 400 text passes; clips are independent), two runs are
+    bit-identical."""
     from helpers import CLASSES_400
     from gava_clip_amd.config import VIT_B16_T16
     m, sd = build(VIT_B16_T16, class_file=CLASSES_400, n_cls=400)
@@ -329,16 +352,23 @@ def test_c3_full_size_batch_is_anchored_to_the_oracle_and_deterministic():
         a = m(x)[0]
         b = m(x)[0]
     assert torch.equal(a, b) and tuple(a.shape) == (32, 400)
-    want = Oracle(VIT_B16_T16, sd, torch.cat(m.tokenized_prompts)).forward(x0)["logits"].numpy()
-    e = rel_to_max(a[:1].cpu().numpy(), want)
-    print(f"\n[c3 full size] clip 0 vs oracle {e:.3e}; argmax {int(a[0].argmax())} vs {int(want[0].argmax())}")
+    g = np.load(os.path.join(golden_dir, "c3_clip0.npz"))
+    want = g["logits"]
+    lg = a[:1].cpu().numpy()
+    e, viol = rel_to_max(lg, want), mixed_violation(lg, want)
+    print(f"\n[c3 full size] clip 0 vs reference: rel-to-max {e:.3e} mixed {viol:.3f} (400 logits, |ref| {np.abs(want).min():.3f}"
+          f"..{np.abs(want).max():.3f}); text features {rel_to_max(m.text_features.cpu().numpy(), g['text_features']):.3e}; "
+          f"argmax {int(a[0].argmax())} vs {int(want[0].argmax())}")
     assert e < 1e-3
+    assert viol <= 1.0
+    assert rel_to_max(m.text_features.cpu().numpy(), g["text_features"]) < 1e-3
+    assert int(a[0].argmax()) == int(want[0].argmax())
 
 
-def test_c5_full_size_vit_l14_t32_is_anchored_to_the_oracle_and_deterministic():
+def test_c5_full_size_vit_l14_t32_is_anchored_to_the_reference_and_deterministic(golden_dir):
     """BASELINE config c5 per GPU (ViT-L/14: D=1024, 16 heads, 24 blocks, P=14 -> 257 tokens per frame, T=32 -> 298
     attention keys, text width 768 / 12 heads; 32 clips = 1024 frames = 263 168 rows): the logits of clip 0 meet the
-    oracle's for that clip alone (clips are independent; ~5.6 TFLOP on the host cores), two runs are bit-identical."""
+    REFERENCE's for that clip alone (tests/golden/c5_clip0.npz; clips are independent), two runs are bit-identical."""
     from gava_clip_amd.config import VIT_L14_T32
     cfg = VIT_L14_T32
     m, sd = build(cfg)
@@ -353,14 +383,15 @@ def test_c5_full_size_vit_l14_t32_is_anchored_to_the_oracle_and_deterministic():
         b = m(x)[0]
         alone = m(x[:1])[0]
     assert torch.equal(a, b) and tuple(a.shape) == (32, 3) and bool(torch.isfinite(a).all())
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    want = Oracle(cfg, sd, torch.cat(m.tokenized_prompts)).forward(x0)
-    e = rel_to_max(a[:1].cpu().numpy(), want["logits"].numpy())
-    e1 = rel_to_max(alone.cpu().numpy(), want["logits"].numpy())
-    ev = rel_to_max(m.last["video_features"][:1].cpu().numpy(), want["video_features"].numpy())
-    print(f"\n[c5 full size] clip 0 of 32 vs oracle {e:.3e}; run alone {e1:.3e}; video features (alone) {ev:.3e}; "
-          f"logits {a[0].cpu().numpy()} vs {want['logits'].numpy()[0]}")
+    g = np.load(os.path.join(golden_dir, "c5_clip0.npz"))
+    e = rel_to_max(a[:1].cpu().numpy(), g["logits"])
+    e1 = rel_to_max(alone.cpu().numpy(), g["logits"])
+    ev = rel_to_max(m.last["video_features"][:1].cpu().numpy(), g["video_features"])
+    viol = mixed_violation(a[:1].cpu().numpy(), g["logits"])
+    print(f"\n[c5 full size] clip 0 of 32 vs reference {e:.3e} (mixed {viol:.3f}); run alone {e1:.3e}; video features (alone) {ev:.3e}; "
+          f"logits {a[0].cpu().numpy()} vs {g['logits'][0]}")
     assert e < 1e-3 and e1 < 1e-3
+    assert viol <= 1.0
 
 
 def test_split_precision_last_block_is_an_exact_option(golden_dir):

@@ -77,6 +77,26 @@ def test_oracle_c1_vit_b16(golden_dir):
     assert np.array_equal(r["logits"].argmax(-1).numpy(), g["logits"].argmax(-1))
 
 
+@pytest.mark.parametrize("name", ["c1_b16_s1", "c1_b16_s2", "c1_b16_s3", "c3_clip0", "c5_clip0"])
+def test_oracle_vs_round3_reference_fixtures(golden_dir, name):
+    """The round-3 reference runs (tools/gen_golden.py --round3): three more weight + input seeds at c1, clip 0 of c3
+    (16 frames, 400 classes) and of c5 (ViT-L/14, 32 frames).  Pins the oracle at the shapes the full-size GPU tests
+    compare against."""
+    from helpers import golden_case
+    from gava_clip_amd.tokenizer import read_class_names, prompt_texts
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    cfg, class_file, n_cls, B, wseed, xseed = golden_case(name)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    assert int(g["wseed"]) == wseed and int(g["xseed"]) == xseed
+    x = synth.synth_clip(B, cfg.num_frames, cfg.input_size, seed=xseed)
+    assert abs(float(x.astype(np.float64).sum()) - g["x_checksum"][0]) < 1e-6
+    tokens = tokenize(prompt_texts(read_class_names(class_file), cfg.text_num_prompts))
+    r = Oracle(cfg, synth_torch_state(cfg, n_cls, wseed), tokens).forward(torch.from_numpy(x))
+    for k in ("logits", "video_features", "text_features", "summary"):
+        assert rel_to_max(r[k].numpy(), g[k]) < TOL, k
+    assert np.array_equal(r["logits"].argmax(-1).numpy(), g["logits"].argmax(-1))
+
+
 def test_oracle_gradients_match_reference_tiny(golden_dir):
     """The oracle under torch autograd against the gradients the REFERENCE computed for the same loss
     (tests/golden/tiny_grads.npz, tools/gen_golden.py run_grad_case): pins the checker of the HIP backward."""
