@@ -69,6 +69,9 @@ struct GemmParams {
   int sm, sn;   // super-tile shape (in tiles)
   unsigned long long* dbg;  // debug only: per-wave segment cycle sums (gava_debug_set_buffer)
   int cu_reserve;   // persistent kernels: CUs left out of the grid (gava_gemm_args.cu_reserve)
+  int kernel;       // gava_gemm_args.kernel
+  int pair_delay;   // experiment builds: start delay of a CU's second workgroup, 10 ns ticks
+  int pair_sleep;   // experiment builds: s_sleep units after every epilogue chunk
   int ablate;   // timing probes, always 0 unless built with -DGAVA_ENABLE_ABLATE: 1 = no staging loads after the prologue,
                 // 2 = no LDS reads/MFMA, 4 = no epilogue
 };
@@ -994,10 +997,325 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// v4 "pair": persistent 128 x 256 kernel for the fp32-output GEMMs with a heavy epilogue (out_proj, fc2 and the dgrad
+// GEMMs: fp32 residual read + fp32 write + 16-bit copy + row sums = 10 bytes per output element), run as TWO independent
+// 256-thread workgroups per CU.  The 256^2 kernel above has one workgroup per CU whose eight waves reach the epilogue
+// together: its 640 KB per tile leave the CU while the matrix pipe idles (out_proj: k-loop 0.12 ms + epilogue 0.15 ms).
+// Two co-resident workgroups fall out of phase by themselves - a workgroup stuck in its stores leaves the SIMDs' MFMA
+// issue slots to the other one - so one tile's epilogue traffic drains under the other tile's k-loop.
+//   * 4 waves as 4(M) x 1(N): a wave owns 32 rows x all 256 columns (2 x 16 accumulators = 128 VGPRs).  Its A rows are
+//     nobody else's, so the A operand never enters the LDS: each lane fetches its MFMA fragment (row fr, 16 bytes of k)
+//     straight from global memory, one stage ahead, into registers.  Only W (shared by the four waves) is staged by
+//     LDS-DMA: 32 KiB per 64-deep stage, 2 stages = 64 KiB per workgroup, which is what lets two workgroups share a CU
+//     (the 256^2 kernel's ring is 128 KiB).  LDS-DMA issue per MFMA is the same as in the 256^2 kernel (8 pieces per wave
+//     and stage), LDS reads are 0.5 instead of 0.375 ds_read_b128 per MFMA.
+//   * a wave holds whole 256-column row segments, so the LayerNorm row sums of the folding producers need no exchange
+//     between waves: in-lane sum, two permlane swaps, one float2 per row and 256-column tile (the rowsum_reduced layout).
+//   * natural column order (lane (fr, fg) holds columns 16 jj + 4 fg + r): residual loads and fp32 stores move 64
+//     contiguous bytes per row and instruction; the 16-bit copy is staged through a wave-private 2 KiB LDS block so that it
+//     leaves as whole 128-byte row segments; the bias sits in LDS (once per launch).
+//   * every wait is vmcnt(0): inside a workgroup the epilogue's stores and the next tile's residual loads drain before
+//     the next k-loop starts (loads and stores retire out of order with each other, a counted wait would not be safe
+//     here) - the overlap comes from the other workgroup, not from within.
+template <class P>
+__global__ __launch_bounds__(256, 2)
+void gemm_pair_kernel(const GemmParams p) {
+  constexpr int BM = 128, BN = 256, NW = 4;
+  constexpr int WSTAGE = BN * BK * 2;                       // 32 KiB
+  constexpr int PPW = BN / 8 / NW;                          // 8 LDS-DMA pieces (1 KiB = 8 W rows) per wave and stage
+  constexpr int XS_PITCH = 128, XS_WAVE = 16 * XS_PITCH;    // 16-bit copy staging: 16 rows x 128 B per wave
+  constexpr int XS_OFF = 2 * WSTAGE, BIAS_OFF = XS_OFF + NW * XS_WAVE;
+  __shared__ __attribute__((aligned(16))) char smem[BIAS_OFF + 4096];   // 76 KiB: two workgroups per CU
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // bias of all N <= 1024 columns, once
+  {
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && tid * 4 < p.N) b4 = *reinterpret_cast<const float4*>(p.bias + tid * 4);
+    *reinterpret_cast<float4*>(smem + BIAS_OFF + tid * 16) = b4;
+  }
+  __syncthreads();
+
+  // ---- this workgroup's tiles: XCD-contiguous range, strided by the workgroups of the XCD (as the 256^2 kernel)
+  const int nwg = p.n_tiles, nb = gridDim.x;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = nb >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int x_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int x_count = xcd < r ? q + 1 : q;
+  const int my_tiles = slot < x_count ? (x_count - slot + per_xcd - 1) / per_xcd : 0;
+  if (my_tiles == 0) return;
+  const int nk = p.K / BK;
+  const int G = my_tiles * nk;
+  auto tile_coords = [&](int j, int& m0, int& n0) {
+    const int wg = x_first + slot + j * per_xcd;
+    const int per_group = p.sm * p.tiles_n;
+    const int g = wg / per_group, first_m = g * p.sm;
+    const int sm = min(p.sm, p.tiles_m - first_m);
+    const int w = wg - g * per_group;
+    const int chunk = w / (sm * p.sn), rr = w - chunk * (sm * p.sn);
+    m0 = (first_m + rr % sm) * BM;
+    n0 = (chunk * p.sn + rr / sm) * BN;
+  };
+
+  // 32-bit element offsets from p.W / p.A (host guarantees they fit).  A wave's W pieces i = 0..7 are the rows
+  // (wave + 4 i) * 8 + (lane >> 3): 32 rows apart, so they share the swizzle term ((row >> 1) & 7) and ONE lane-dependent
+  // offset serves all eight (piece i adds the uniform 32 i ldw)
+  unsigned wsrc, asrc[2];
+  auto set_src = [&](int m0, int n0) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));   // recomputed per tile instead of hoisted (registers), as in the 256^2 kernel
+    {
+      const int row = wave * 8 + (ln >> 3);
+      const int chunk = (ln & 7) ^ ((row >> 1) & 7);
+      wsrc = (unsigned)(n0 + row) * (unsigned)p.ldw + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int gm = m0 + wave * 32 + i * 16 + (ln & 15);
+      gm = gm < p.M ? gm : p.M - 1;
+      asrc[i] = (unsigned)gm * (unsigned)p.lda + (ln >> 4) * 8;
+    }
+  };
+  // A fragments [k half][row group]: two register sets, stage g computes from set g & 1 while the loads of stage g+1 land
+  // in the other one (the stage loop is unrolled by two; K % 128 == 0 is the launcher's condition)
+  s16x8_t aA[2][2], aB[2][2];
+  auto issue = [&](int g, int kt, s16x8_t (&an)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(p.W + (size_t)(unsigned)(i * 32 * (int)p.ldw + kt * BK) + (size_t)wsrc),
+                                       LDS_PTR(void, smem + (g & 1) * WSTAGE + (wave + i * NW) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        an[ks][i] = *reinterpret_cast<const s16x8_t*>(p.A + (size_t)(asrc[i] + (unsigned)(kt * BK + ks * 32)));
+  };
+  // W fragment jj, k half ks: rows 16 jj + fr of the stage, 16-byte chunk (4 ks + fg) ^ ((row >> 1) & 7)
+  const int w_row = fr * 128;
+  const int w_k0 = (fg ^ (fr >> 1)) << 4, w_k1 = ((4 + fg) ^ (fr >> 1)) << 4;
+
+  f32x4_t acc[2][16];
+  auto load_resid = [&](int i, int c, int mm0, int nn0) {   // rows mm0 + wave*32 + i*16 + fr, columns nn0 + 64 c + 16 q + 4 fg ..
+    if (p.resid) {
+      int m = mm0 + wave * 32 + i * 16 + fr;
+      m = m < p.M ? m : p.M - 1;
+      const float* rp = p.resid + (long)m * p.ldr + nn0 + 64 * c + 4 * fg;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) acc[i][4 * c + qq] = *reinterpret_cast<const f32x4_t*>(rp + 16 * qq);
+    } else {
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) acc[i][4 * c + qq] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  int m0, n0, m0n = 0, n0n = 0;
+  tile_coords(0, m0, n0);
+  set_src(m0, n0);
+  int role = 0; (void)role;
+#ifdef GAVA_ENABLE_ABLATE   // experiment builds: GAVA_PAIR_MODE bits, GAVA_PAIR_DELAY in 10 ns ticks (launch_pair)
+  {
+    // which of the CU's two workgroups is this?  bit 1: by the wave slot the hardware gave wave 0 (HW_ID[3:0]), else by
+    // the position in the XCD's dispatch order (second half = second workgroup of a CU if the dispatcher goes breadth-first)
+    const unsigned hw = __builtin_amdgcn_s_getreg(63492);   // hwreg(HW_REG_HW_ID, 0, 32)
+    const bool second = (p.ablate & 2) ? (hw & 15u) != 0 : slot >= per_xcd / 2;
+    if ((p.ablate & 1) && second) {
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (unsigned long long)p.pair_delay) __builtin_amdgcn_s_sleep(32);
+    }
+    if (((p.ablate & 4) && !second) || ((p.ablate & 32) && second)) __builtin_amdgcn_s_setprio(2);
+    // 64: split roles - a CU's first workgroup runs only k-loops, its second only epilogues (can the two phases overlap at
+    // all?); 128 / 256 with it: the epilogue / the k-loop group leaves at once (each role's time alone)
+    if (p.ablate & 64) {
+      if (((p.ablate & 128) && second) || ((p.ablate & 256) && !second)) return;
+      role = second ? 16 : 8;
+    }
+  }
+#endif
+  issue(0, 0, aA);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) load_resid(i, c, m0, n0);
+
+  // one 64-deep stage: everything this wave has in flight lands (its W pieces and A fragments of this stage, after an
+  // epilogue also that tile's stores and this tile's residual loads), the barrier makes the other waves' pieces visible
+  // and frees the other ring slot, the next stage's loads go out, 64 MFMAs
+  auto stage = [&](int j, int kt, s16x8_t (&ac)[2][2], s16x8_t (&an)[2][2]) {
+    const int g = j * nk + kt;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only (expcnt 7, lgkmcnt 15: untouched)
+    __builtin_amdgcn_s_barrier();
+    if (g + 1 < G) {
+      if (kt + 1 < nk) {
+        issue(g + 1, kt + 1, an);
+      } else {
+        tile_coords(j + 1, m0n, n0n);
+        set_src(m0n, n0n);
+        issue(g + 1, 0, an);
+      }
+    }
+    const char* cur = smem + (g & 1) * WSTAGE + w_row;
+    // 8 steps of (4 W fragments x 2 row groups); the fragments of step s+1 are read while step s multiplies
+    s16x8_t wf[2][4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) wf[0][qq] = *reinterpret_cast<const s16x8_t*>(cur + qq * 2048 + w_k0);
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int ks = st >> 2, grp = st & 3;
+      if (st < 7) {
+        const int ks1 = (st + 1) >> 2, grp1 = (st + 1) & 3;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          wf[(st + 1) & 1][qq] = *reinterpret_cast<const s16x8_t*>(cur + (4 * grp1 + qq) * 2048 + (ks1 ? w_k1 : w_k0));
+      }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][4 * grp + qq] = P::mfma(wf[st & 1][qq], ac[ks][i], acc[i][4 * grp + qq]);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int st = 0; st < 7; ++st) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+  };
+
+  for (int j = 0; j < my_tiles; ++j) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      if ((ABLATE | role) & 16) break;   // experiment builds: epilogue only
+      stage(j, kt, aA, aB);
+      stage(j, kt + 1, aB, aA);
+    }
+    if ((ABLATE | role) & 8) continue;   // experiment builds: k-loop only
+
+    // ---- epilogue of tile j: lane holds out[m][n0 + 16 jj + 4 fg + r], m = m0 + wave*32 + i*16 + fr
+    // every lane-dependent address is derived here from an opaque copy of the lane id: hoisted out of the tile loop these
+    // terms stay live across the k-loop, spill, and every spill reload is a vmcnt wait (as in the 256^2 kernel)
+    const bool has_next = j + 1 < my_tiles;
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int er = le & 15, eg = le >> 4;
+    char* xs = smem + XS_OFF + wave * XS_WAVE;
+    const int xs_w = er * XS_PITCH + (eg & 1) * 8, xs_sw = (er >> 1) & 7, xs_hi = eg >> 1;
+    const int xr_row = le >> 3, xr_chunk = le & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wave * 32 + i * 16 + er;
+      const bool valid = m < p.M;
+      float* orow = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n0 + 4 * eg;
+      float ps1 = 0.f, ps2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4* bp = reinterpret_cast<const float4*>(smem + BIAS_OFF + (n0 + 64 * c + 4 * eg) * 4);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const float4 b = bp[4 * qq];
+          const f32x4_t a = acc[i][4 * c + qq];
+          const float v0 = a[0] + b.x, v1 = a[1] + b.y, v2 = a[2] + b.z, v3 = a[3] + b.w;
+          if (valid) *reinterpret_cast<float4*>(orow + 64 * c + 16 * qq) = make_float4(v0, v1, v2, v3);
+          if (p.x16) {
+            *reinterpret_cast<uint2*>(xs + xs_w + (((2 * qq + xs_hi) ^ xs_sw) << 4)) = pack4<P>(v0, v1, v2, v3);
+            ps1 += (v0 + v1) + (v2 + v3);
+            ps2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+          }
+        }
+        if (p.x16) {
+          // lane l: row (l >> 3) (+8 in the second pass), 16-byte chunk (l & 7) of the 128-byte row segment
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int row = xr_row + 8 * h;
+            const uint4 d = *reinterpret_cast<const uint4*>(xs + row * XS_PITCH + ((xr_chunk ^ ((row >> 1) & 7)) << 4));
+            const int mm = m0 + wave * 32 + i * 16 + row;
+            if (mm < p.M) *reinterpret_cast<uint4*>(p.x16 + (long)mm * p.ldx16 + n0 + 64 * c + xr_chunk * 8) = d;
+          }
+        }
+#ifdef GAVA_ENABLE_ABLATE   // experiment builds: a throttled epilogue (GAVA_PAIR_MODE bit 512, GAVA_PAIR_SLEEP x 64 cycles per chunk)
+        if (p.ablate & 512) for (int z = 0; z < p.pair_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+#endif
+        // next tile: its residual rows go straight into the accumulators just freed
+        if (has_next) {
+          if (p.resid) {
+            int mn = m0n + wave * 32 + i * 16 + er;
+            mn = mn < p.M ? mn : p.M - 1;
+            const float* rp = p.resid + (long)mn * p.ldr + n0n + 64 * c + 4 * eg;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) acc[i][4 * c + qq] = *reinterpret_cast<const f32x4_t*>(rp + 16 * qq);
+          } else {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) acc[i][4 * c + qq] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+      if (p.x16) {
+        // the 4 lanes that share a row (fg = 0..3) cover its 256 columns: one (sum, sum^2) per row and 256-column tile
+        ps1 = sum_across_lane_groups(ps1); ps2 = sum_across_lane_groups(ps2);
+        if (eg == 0 && valid) p.rowsum[(long)m * 4 + n0 / 256] = make_float2(ps1, ps2);
+      }
+    }
+    m0 = m0n; n0 = n0n;
+  }
+}
+
+template <class P>
+int launch_pair(GemmParams gp, hipStream_t s) {
+  gp.tiles_m = (gp.M + 127) / 128;
+  gp.tiles_n = gp.N / 256;
+  gp.n_tiles = gp.tiles_m * gp.tiles_n;
+  // super-tile: ~64 concurrent tiles per XCD; the sn W panels (all of them for N <= 1024) and sm A panels share its L2
+  gp.sn = gp.tiles_n < 4 ? gp.tiles_n : 4;
+  gp.sm = 64 / gp.sn;
+  if (gp.sm > gp.tiles_m) gp.sm = gp.tiles_m;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GAVA_ELAUNCH;
+    n_cu = prop.multiProcessorCount / 8 * 8;
+    if (n_cu <= 0) n_cu = 8;
+  }
+  static const int forced = getenv("GAVA_CU_RESERVE") ? atoi(getenv("GAVA_CU_RESERVE")) : -1;
+  const int reserve = forced >= 0 ? forced : (gp.cu_reserve > 0 ? gp.cu_reserve : 0);
+  const int avail = 2 * (n_cu - reserve > 8 ? (n_cu - reserve) / 8 * 8 : 8);   // two workgroups per CU
+  const int blocks = gp.n_tiles < avail ? (gp.n_tiles + 7) / 8 * 8 : avail;
+#ifdef GAVA_ENABLE_ABLATE
+  static const int pmode = getenv("GAVA_PAIR_MODE") ? atoi(getenv("GAVA_PAIR_MODE")) : 0;
+  static const int pdelay = getenv("GAVA_PAIR_DELAY") ? atoi(getenv("GAVA_PAIR_DELAY")) : 0;
+  static const int psleep = getenv("GAVA_PAIR_SLEEP") ? atoi(getenv("GAVA_PAIR_SLEEP")) : 0;
+  gp.ablate = pmode; gp.pair_delay = pdelay; gp.pair_sleep = psleep;
+#endif
+  hipLaunchKernelGGL((gemm_pair_kernel<P>), dim3(blocks), dim3(256), 0, s, gp);
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+
 template <class P>
 int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   static const int variant = getenv("GAVA_GEMM_VARIANT") ? atoi(getenv("GAVA_GEMM_VARIANT")) : 0;
-  if (gp.rowsum_reduced || gp.fpart) {   // only the persistent kernel implements these; never fall back silently
+  // fp32-output GEMMs with the heavy epilogue (residual stream, folding producers): the two-workgroups-per-CU kernel can
+  // be named explicitly (gava_gemm_args.kernel) or switched on for big M with GAVA_GEMM_VARIANT=4
+  {
+    const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
+    const long tiles128 = (long)((gp.M + 127) / 128) * (gp.N / 256);
+    const bool can_pair = epi == GAVA_EPI_F32 && gp.N % 256 == 0 && gp.N <= 1024 && gp.K % 128 == 0 && fits && !gp.frames &&
+                          !gp.clips && (gp.rowsum_reduced || !gp.x16);
+    if (gp.kernel == GAVA_KERNEL_PAIR) return can_pair ? launch_pair<P>(gp, s) : GAVA_EINVAL;
+    if (gp.kernel == GAVA_KERNEL_256) {
+      const bool can_256 = gp.N % 256 == 0 && fits && !gp.frames && !gp.clips;
+      return can_256 ? launch_256<P, 3>(gp, epi, s) : GAVA_EINVAL;
+    }
+    if (gp.kernel != GAVA_KERNEL_AUTO) return GAVA_EINVAL;
+    // Measured in round 3 (profiles/r03_pair_*.txt): the pair kernel does not win - out_proj 0.299 vs 0.276 ms, fc2 0.69 vs 0.575 ms
+    // on the 256^2 kernel; the epilogue of one workgroup does not drain under the k-loop of the other.  It stays selectable
+    // (GAVA_GEMM_VARIANT=4 for whole-forward A/B, gava_gemm_args.kernel for tests) and is NOT taken automatically.
+    (void)tiles128;
+    if (can_pair && variant == 4 && tiles128 >= 1024 && (gp.resid || gp.x16)) return launch_pair<P>(gp, s);
+  }
+  if (gp.rowsum_reduced || gp.fpart) {   // only the persistent kernels implement these; never fall back silently
     const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
     return (gp.N % 256 == 0 && fits && !gp.frames && !gp.clips) ? launch_256<P, 3>(gp, epi, s) : GAVA_EINVAL;
   }
@@ -1074,6 +1392,8 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.clips = patch_u8 ? a->clips : nullptr; gp.clut = a->clip_lut;
   gp.split_out = a->split_out;
   gp.cu_reserve = a->cu_reserve;
+  gp.kernel = a->kernel;
+  gp.pair_delay = 0; gp.pair_sleep = 0;
 #ifdef GAVA_ENABLE_ABLATE   // timing-probe builds only (tools/ab_build.sh NAME -DGAVA_ENABLE_ABLATE): results are WRONG by design
   static const int ablate = getenv("GAVA_GEMM_ABLATE") ? atoi(getenv("GAVA_GEMM_ABLATE")) : 0;
   gp.ablate = ablate;

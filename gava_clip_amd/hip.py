@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAVA_HIP_LIB") or os.path.join(_HERE, "libgava_hip.so")   # env: A/B experiment builds only
 
 PREC_F16, PREC_BF16 = 0, 1
+KERNEL_AUTO, KERNEL_256, KERNEL_PAIR = 0, 3, 4     # gava_gemm_args.kernel
 EPI_H16, EPI_H16_QGELU, EPI_F32, EPI_F32_PATCH, EPI_H16_QGELU_BWD = 0, 1, 2, 3, 4
 PREC_NAMES = {"fp16": PREC_F16, "f16": PREC_F16, "bf16": PREC_BF16}
 PREC_TORCH = {PREC_F16: torch.float16, PREC_BF16: torch.bfloat16}
@@ -37,7 +38,7 @@ class GemmArgs(C.Structure):
                 ("x16_out", _vp), ("ld_x16", C.c_int64), ("rowsum_out", _fp),
                 ("fold_stats", _fp), ("fold_s", _fp), ("fold_t", _fp), ("cu_reserve", C.c_int),
                 ("rowsum_reduced", C.c_int), ("fold_partials", _fp),
-                ("clips", _vp), ("clip_lut", _fp)]
+                ("clips", _vp), ("clip_lut", _fp), ("kernel", C.c_int)]
 
 
 class LayerNormArgs(C.Structure):
@@ -237,8 +238,9 @@ def h16_dtype(prec):
 def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0,
          pos=None, time=None, n_patches=0, T=0, M=None, split_out=False, frames=None, frame_size=0, patch=0, aux=None,
          aux_prec=None, aux_out=None, x16_out=None, rowsum_out=None, fold_stats=None, fold_s=None, fold_t=None,
-         cu_reserve=0, rowsum_reduced=False, fold_partials=None, clips=None, clip_lut=None):
+         cu_reserve=0, rowsum_reduced=False, fold_partials=None, clips=None, clip_lut=None, kernel=0):
     a = GemmArgs()
+    a.kernel = kernel
     a.clips, a.clip_lut = ptr(clips), ptr(clip_lut)
     a.cu_reserve = cu_reserve
     a.rowsum_reduced, a.fold_partials = int(rowsum_reduced), ptr(fold_partials)

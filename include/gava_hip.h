@@ -113,7 +113,7 @@ typedef struct {
   /* LayerNorm folding without the gava_row_stats launch in between (big-M GEMMs: the persistent kernel only; N % 256 == 0,
    * N <= 1024; anything else is rejected, never silently routed to another path).  Producer: rowsum_reduced != 0 makes
    * rowsum_out float2 [ceil(M/256)*256][4] - slot n/256 of row m holds (sum x, sum x^2) over columns [256*(n/256), +256),
-   * the four waves' partials added in a fixed order.  Consumer: fold_partials = that array (instead of fold_stats); the
+   * partial sums added in a fixed order.  Consumer: fold_partials = that array (instead of fold_stats); the
    * kernel derives (mean, rstd) of its rows itself (eps 1e-5, variance = E[x^2] - mean^2, fixed summation order). */
   int rowsum_reduced;
   const float* fold_partials;
@@ -121,7 +121,16 @@ typedef struct {
    * [M / (n_patches * T)], frame_size = the crop size, clip_lut = device fp32 [3][256]: lut[c][v] = (v/255 - mean[c]) / std[c]
    * as the caller's fp32 arithmetic gives it (the reference's own torch expression: the normalisation is then exact). */
   const gava_clip_desc* clips; const float* clip_lut;
+  /* Kernel selection.  0 = automatic (by shape and epilogue, the only value the forward drivers pass).  Tests and A/B
+   * timing may name a kernel: GAVA_KERNEL_256 = the persistent 256 x 256 kernel (one 512-thread workgroup per CU),
+   * GAVA_KERNEL_PAIR = the persistent 128 x 256 kernel run as two 256-thread workgroups per CU (EPI_F32 only: the
+   * residual-stream GEMMs out_proj / fc2 and their folding-producer form; N % 256 == 0, N <= 1024, K % 128 == 0).  A named
+   * kernel that does not take the shape is rejected (GAVA_EINVAL), never replaced. */
+  int kernel;
 } gava_gemm_args;
+#define GAVA_KERNEL_AUTO 0
+#define GAVA_KERNEL_256 3
+#define GAVA_KERNEL_PAIR 4
 int gava_gemm(const gava_gemm_args* a, gava_stream_t stream);
 
 /* Row LayerNorm (eps 1e-5, affine) fp32 -> h16 and/or fp32; one wave per row.  Replaces

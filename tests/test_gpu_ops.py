@@ -458,3 +458,67 @@ def test_layernorm_fold_with_outlier_channels(mode):
         e_plain = float((plain.float() - full).abs().max()) / scale
         print(f"\n[outliers/{mode}/prec {prec}] max error / max|ref|: folded {e_fold:.2e}, unfolded {e_plain:.2e}")
         assert e_fold < 12 * EPS16[prec], (mode, prec, e_fold)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 768), (4133, 1024, 256), (129, 512, 3072), (7, 768, 128),
+                                   (45056, 768, 768), (33001, 768, 3072)])
+def test_gemm_pair_kernel(prec, M, N, K):
+    """The two-workgroups-per-CU 128 x 256 kernel (gava_gemm_args.kernel = GAVA_KERNEL_PAIR; out_proj / fc2 of the vision
+    blocks take it automatically at full size) named explicitly on small, ragged and full-size shapes: plain fp32 output,
+    fp32 residual (in place and from another buffer with its own stride), and the folding-producer form (16-bit copy +
+    per-256-column row sums) - against torch on the same rounded operands, bit for bit against the 256^2 kernel (same
+    k order: the two kernels differ in tiling only), rows beyond M untouched."""
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    A = rnd((M, K), 1.0, 1).to(d).to(dt)
+    W = rnd((N, K), K ** -0.5, 2).to(d).to(dt)
+    bias = rnd((N,), 0.5, 3).to(d)
+    ref = A.float() @ W.float().t() + bias
+    pad = 256
+    # plain, no bias, rows beyond M must stay
+    out = torch.full((M + pad, N), 7.0, dtype=torch.float32, device=d)
+    hip.gemm(A, W, None, out, epilogue=hip.EPI_F32, prec=prec, M=M, kernel=hip.KERNEL_PAIR)
+    assert torch.all(out[M:] == 7.0)
+    assert torch.allclose(out[:M], ref - bias, rtol=1e-4, atol=1e-4)
+    # residual from another buffer with a wider stride
+    Rbuf = rnd((M, N + 64), 1.0, 4).to(d)
+    out2 = torch.zeros(M, N, dtype=torch.float32, device=d)
+    hip.gemm(A, W, bias, out2, epilogue=hip.EPI_F32, prec=prec, resid=Rbuf[:, :N], kernel=hip.KERNEL_PAIR)
+    assert torch.allclose(out2, Rbuf[:, :N] + ref, rtol=1e-4, atol=1e-4)
+    ref256 = torch.zeros(M, N, dtype=torch.float32, device=d)
+    hip.gemm(A, W, bias, ref256, epilogue=hip.EPI_F32, prec=prec, resid=Rbuf[:, :N], kernel=hip.KERNEL_256)
+    assert torch.equal(out2, ref256)
+    # folding producer, in place
+    Mp = (M + 255) // 256 * 256
+    X = Rbuf[:, :N].contiguous()
+    x16 = torch.full((Mp, N), 3.0, dtype=dt, device=d)
+    part = torch.full((Mp + 32, 4, 2), float("nan"), dtype=torch.float32, device=d)
+    hip.gemm(A, W, bias, X, epilogue=hip.EPI_F32, prec=prec, resid=X, x16_out=x16, rowsum_out=part, rowsum_reduced=True,
+             kernel=hip.KERNEL_PAIR)
+    assert torch.equal(X, out2)
+    assert torch.equal(x16[:M], X.to(dt)) and torch.all(x16[M:] == 3.0)
+    slots = N // 256
+    assert torch.isfinite(part[:M, :slots]).all() and torch.isnan(part[M:]).all() and torch.isnan(part[:, slots:]).all()
+    Xs = X.view(M, slots, 256)
+    assert torch.allclose(part[:M, :slots, 0], Xs.sum(2), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(part[:M, :slots, 1], (Xs * Xs).sum(2), rtol=1e-4, atol=2e-3)
+    # deterministic
+    X2 = Rbuf[:, :N].contiguous()
+    part2 = torch.full_like(part, float("nan"))
+    hip.gemm(A, W, bias, X2, epilogue=hip.EPI_F32, prec=prec, resid=X2, x16_out=x16, rowsum_out=part2, rowsum_reduced=True,
+             kernel=hip.KERNEL_PAIR)
+    assert torch.equal(X, X2) and torch.equal(part[:M, :slots], part2[:M, :slots])
+
+
+def test_gemm_named_kernel_rejects_what_it_does_not_take():
+    d = dev()
+    A = rnd((300, 192)).to(d).half()
+    W = rnd((256, 192)).to(d).half()
+    with pytest.raises(hip.GavaError):       # K % 128 != 0
+        hip.gemm(A, W, None, torch.zeros(300, 256, device=d), epilogue=hip.EPI_F32, prec=hip.PREC_F16, kernel=hip.KERNEL_PAIR)
+    with pytest.raises(hip.GavaError):       # 16-bit output
+        hip.gemm(A[:, :128].contiguous(), W[:, :128].contiguous(), None, torch.zeros(300, 256, device=d).half(),
+                 epilogue=hip.EPI_H16, prec=hip.PREC_F16, kernel=hip.KERNEL_PAIR)
+    with pytest.raises(hip.GavaError):       # unknown kernel id
+        hip.gemm(A, W, None, torch.zeros(300, 256, device=d), epilogue=hip.EPI_F32, prec=hip.PREC_F16, kernel=9)

@@ -7,6 +7,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 abi=$(python -c "from gava_clip_amd.build import abi_hash; print(abi_hash())")
 mkdir -p gava_clip_amd/build/$name
+rm -f gava_clip_amd/build/$name/*.o
 for f in gemm attention rowops forward preprocess backward attention_bwd; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DGAVA_ABI_HASH=$abi "$@" -c gava_clip_amd/csrc/$f.hip -o gava_clip_amd/build/$name/$f.o &
 done
