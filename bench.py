@@ -35,10 +35,10 @@ def log(msg):
 
 
 def kernel_source_hash():
-    """sha256 over the GEMM kernel sources the roofline kernel is built from (recorded by tools/make_traffic.py)."""
+    """sha256 over the kernel sources the per-layer kernels are built from (recorded by tools/make_traffic.py)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm.hip", "common.h"):
+    for f in ("gemm.hip", "common.h", "attention.hip"):
         h.update(open(os.path.join(REPO, "gava_clip_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -141,24 +141,26 @@ def kernel_table(cfg, B, prec, fold=False):
 
     pending = []
 
-    def add(name, fn, flops, bytes_):
-        pending.append((name, fn, flops, bytes_))
+    def add(name, fn, flops, bytes_, inst=None, calls=0, key=None):
+        """inst: the kernel instantiation as rocprofv3 names it (rows with the same inst are one line of a kernel-stats
+        CSV); calls: launches of this shape per forward; key: the entry of profiles/traffic.json"""
+        pending.append((name, fn, flops, bytes_, inst, calls, key))
 
     def measure():
         """Interleaved rounds in one process (every kernel sees the same thermal / clock history; a kernel timed alone
         right after an idle gap or first in a list reads up to 10 % off): 10 warm-up launches each, then 3 rounds of 20
         launches per kernel, median of the rounds."""
-        for _, fn, _, _ in pending:
+        for _, fn, *_ in pending:
             for _ in range(10):
                 fn()
         samples = [[] for _ in pending]
         for _ in range(3):
-            for i, (_, fn, _, _) in enumerate(pending):
+            for i, (_, fn, *_) in enumerate(pending):
                 samples[i].append(event_time_ms(fn, iters=20, warmup=2))
-        for (name, fn, flops, bytes_), sm in zip(pending, samples):
+        for (name, fn, flops, bytes_, inst, calls, key), sm in zip(pending, samples):
             ms = sorted(sm)[1]
             rows.append(dict(kernel=name, ms=round(ms, 4), tflops=round(flops / ms / 1e9, 1) if flops else None,
-                             gbps=round(bytes_ / ms / 1e6, 1), flops=flops, bytes=bytes_))
+                             gbps=round(bytes_ / ms / 1e6, 1), flops=flops, bytes=bytes_, inst=inst, calls=calls, key=key))
 
     Rp = (R + 255) // 256 * 256
     rsum = torch.zeros(Rp, D // 64, 2, dtype=torch.float32, device=d)
@@ -191,16 +193,25 @@ def kernel_table(cfg, B, prec, fold=False):
                 2.0 * R * D * F, R * F * 2 + R * D * 10 + D * F * 2 + R * (D // 64) * 8)}
     X16 = torch.empty(R, D, dtype=dt, device=d)
     first, second = (folded, plain) if fold else (plain, None)
+    # which instantiation each shape runs as (the name rocprofv3 prints; out_proj and fc2 share one), and how often the
+    # inference forward launches it: with the fold, block 0's qkv and the last block run other kernels (forward.hip)
+    Lyr = cfg.num_layers
+    PN = "PrecF16" if prec == hip.PREC_F16 else "PrecBF16"
+    inst = {"qkv": f"gemm256_kernel<{PN}, 0, false, false, {'true' if fold else 'false'}>",
+            "fc1": f"gemm256_kernel<{PN}, 1, false, false, {'true' if fold else 'false'}>",
+            "out": f"gemm256_kernel<{PN}, 2, true, false, false>", "fc2": f"gemm256_kernel<{PN}, 2, true, false, false>"}
+    calls = {"qkv": Lyr - 2 if fold else Lyr - 1, "fc1": Lyr - 1, "out": Lyr - 1, "fc2": Lyr - 1}
     # per-layer order of the forward; the kernels the forward launches come first, at the positions they always had
-    add("layernorm f32->h16 [R,D]", lambda: hip.layernorm(X, gam, bet, out16=Xn, prec=prec), 0, R * D * 6)
-    add(*first["qkv"])
-    add("attention (frame,head) 197q x %dk" % cfg.attn_keys(),
+    add("layernorm f32->h16 [R,D]", lambda: hip.layernorm(X, gam, bet, out16=Xn, prec=prec), 0, R * D * 6, "layernorm_kernel", 0, None)
+    add(*first["qkv"], inst["qkv"], calls["qkv"], "qkv")
+    add("attention (frame,head) %dq x %dk" % (n1, cfg.attn_keys()),
         lambda: hip.attention(QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:], MIX, batch=BT, heads=H, n_q=n1, n_kmain=n1, prec=prec,
                               side_k=side[:, :D], side_v=side[:, D:], n_g=G, T=T, has_summary=True),
-        4.0 * BT * H * n1 * cfg.attn_keys() * 64, R * 3 * D * 2 + R * D * 2)
-    add(*first["out"])
-    add(*first["fc1"])
-    add(*first["fc2"])
+        4.0 * BT * H * n1 * cfg.attn_keys() * 64, R * 3 * D * 2 + R * D * 2,
+        f"attention_persist_kernel<{PN}, 14, 13>" if cfg.attn_keys() <= 224 else f"attention_kernel<{PN}, 20, false, true, 14>", Lyr - 1, "attn")
+    add(*first["out"], inst["out"], calls["out"], "out")
+    add(*first["fc1"], inst["fc1"], calls["fc1"], "fc1")
+    add(*first["fc2"], inst["fc2"], calls["fc2"], "fc2")
     if fold:
         for k in ("qkv", "out", "fc1", "fc2"):   # the unfolded forms (training, GAVA_LN_FOLD=0), for comparison
             add(*second[k])
@@ -393,53 +404,101 @@ def main():
         fold = bool(getattr(model, "fold_layernorm", False))
         rows = kernel_table(cfg, B, model.prec, fold=fold)
         out["kernels"] = [{k: r[k] for k in ("kernel", "ms", "tflops", "gbps")} for r in rows]
-        # the roofline kernel is the fc1 GEMM in the form the forward launches it (LayerNorm folded into it or not)
-        fc1 = next(r for r in rows if r["kernel"].startswith("gemm fc1  folded" if fold else "gemm fc1"))
+        # ---- roofline: the kernel INSTANTIATION with the largest share of the forward's GPU time (what the first row of a
+        # rocprofv3 --kernel-trace --stats summary of this command shows; out_proj and fc2 of the vision blocks are one
+        # instantiation).  Its members are priced separately: out_proj is HBM-bound, the others MFMA-bound.
+        groups = {}
+        for r in rows:
+            if r["inst"] and r["calls"]:
+                groups.setdefault(r["inst"], []).append(r)
+        share = {k: sum(r["ms"] * r["calls"] for r in v) for k, v in groups.items()}
+        dom = max(share, key=share.get)
+        members = groups[dom]
         # HBM bytes / launch from the committed PMC passes (tools/make_traffic.py writes them together with a hash of the
         # kernel sources they were measured on): a file measured on other sources is stale and is NOT reported
-        traffic, traffic_src = None, "profiles/traffic.json missing"
+        tj, traffic_src = {}, "profiles/traffic.json missing"
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("kernel_source_sha256") == kernel_source_hash():
-                traffic, traffic_src = tj.get("gemm_fc1_bytes_per_launch"), tj.get("source")
+            if tj.get("kernel_source_sha256") == kernel_source_hash() and a.config == tj.get("config", "c2"):
+                traffic_src = tj.get("source")
             else:
-                traffic_src = "profiles/traffic.json is stale (kernel sources changed since its PMC passes): not reported"
-        # cross-check where it runs: HIP-event pairs around every fc1 launch inside a few more forwards of the timed
-        # workload (gava_probe_fc1_*, on the stream the driver launches on) -> roofline.in_forward_ms_per_launch
-        in_fwd = None
-        try:
-            import ctypes as C_
-            from gava_clip_amd import hip as hip_
-            lib_ = hip_.load()
-            gather_was = model.gather_across_ranks
-            model.gather_across_ranks = False      # rank 0 runs these forwards alone: no collective may be entered
-            lib_.gava_probe_fc1_enable(1)
-            samples = []
+                tj, traffic_src = {}, "profiles/traffic.json is stale (kernel sources changed since its PMC passes, or another config): not reported"
+
+        def traffic_of(key):
+            e = tj.get("kernels", {}).get(key)
+            return e.get("bytes_per_launch") if e else None
+
+        # cross-check where they run: HIP-event pairs around every launch of a member inside a few more forwards of the
+        # timed workload (gava_probe_fc1_*, on the stream the driver launches on)
+        def in_forward_ms(which):
             try:
-                for _ in range(5):
-                    step()
-                    buf = (C_.c_float * 64)()
-                    n_ = lib_.gava_probe_fc1_read(buf, 64)
-                    samples += [buf[i] for i in range(n_)]
-            finally:
-                lib_.gava_probe_fc1_enable(0)
-                model.gather_across_ranks = gather_was
-            if samples:
-                in_fwd = sum(samples) / len(samples)
-        except Exception as e:   # the probe must never break the bench line
-            log(f"in-forward fc1 probe skipped: {e}")
-        fc1_ms = fc1["ms"]
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm256_kernel<PrecF16|PrecBF16, EPI_H16_QGELU%s> (vision fc1, M=%d N=%d K=%d)" % (
-                               ", FOLD" if fold else "", B * cfg.num_frames * cfg.tokens_main, cfg.mlp_dim, cfg.feature_dim),
-                           "achieved": round(fc1["flops"] / fc1_ms / 1e9, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(fc1["flops"] / fc1_ms / 1e9 / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
-                           "traffic_source": traffic_src,
-                           "flops_per_launch": fc1["flops"], "ms_per_launch": round(fc1_ms, 4),
-                           "timed": "HIP events around 20 back-to-back launches, median of 3 rounds interleaved with the other per-layer kernels, after 10 warm-up launches",
-                           # the same kernel bracketed by an event pair per launch inside 5 forwards of the timed workload
-                           # (includes ~10-20 us of event/dispatch latency per pair, which the back-to-back figure amortises)
-                           "in_forward_ms_per_launch": round(in_fwd, 4) if in_fwd else None}
+                import ctypes as C_
+                from gava_clip_amd import hip as hip_
+                lib_ = hip_.load()
+                lib_.gava_probe_fc1_enable(which)
+                samples = []
+                try:
+                    for _ in range(5):
+                        step()
+                        buf = (C_.c_float * 64)()
+                        n_ = lib_.gava_probe_fc1_read(buf, 64)
+                        samples += [buf[i] for i in range(n_) if buf[i] >= 0]
+                finally:
+                    lib_.gava_probe_fc1_enable(0)
+                return sum(samples) / len(samples) if samples else None
+            except Exception as e:   # the probe must never break the bench line
+                log(f"in-forward probe skipped: {e}")
+                return None
+        PROBE = {"fc1": 1, "out": 2, "fc2": 3, "qkv": 4, "attn": 5}
+        PEAK_HBM_GBPS, ACHIEVABLE_HBM_GBPS = 8000.0, 6300.0      # MI355X_MICROARCH.md "HBM"
+        mem = []
+        for r in members:
+            infwd = in_forward_ms(PROBE[r["key"]])
+            e = {"kernel": r["kernel"], "launches_per_forward": r["calls"], "ms_per_launch": r["ms"],
+                 "in_forward_ms_per_launch": round(infwd, 4) if infwd else None,
+                 "flops_per_launch": r["flops"], "algorithmic_bytes_per_launch": r["bytes"], "traffic": traffic_of(r["key"])}
+            t_mfma, t_hbm = r["flops"] / (PEAK_MFMA_TFLOPS * 1e9), r["bytes"] / (PEAK_HBM_GBPS * 1e6)     # ms at the two roofs
+            if t_hbm > t_mfma:
+                e.update(bound="hbm", achieved=round(r["bytes"] / r["ms"] / 1e6, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                         frac=round(r["bytes"] / r["ms"] / 1e6 / PEAK_HBM_GBPS, 4),
+                         frac_of_achievable=round(r["bytes"] / r["ms"] / 1e6 / ACHIEVABLE_HBM_GBPS, 4))
+            else:
+                e.update(bound="mfma", achieved=round(r["flops"] / r["ms"] / 1e9, 1), peak=PEAK_MFMA_TFLOPS, unit="TFLOP/s",
+                         frac=round(r["flops"] / r["ms"] / 1e9 / PEAK_MFMA_TFLOPS, 4))
+            mem.append(e)
+        n_calls = sum(r["calls"] for r in members)
+        avg_ms = sum(r["ms"] * r["calls"] for r in members) / n_calls                 # what a kernel-stats row averages
+        avg_flops = sum(r["flops"] * r["calls"] for r in members) / n_calls
+        infw = [e["in_forward_ms_per_launch"] for e in mem]
+        tr = [e["traffic"] for e in mem]
+        fwd_ms = 1e3 * secs / a.steps
+        out["roofline"] = {
+            "bound": "mfma", "kernel": dom + " = " + " + ".join(r["kernel"].split("  ")[0].replace("gemm ", "") for r in members) + " of the vision blocks",
+            "why": "largest share of the forward's GPU time among the kernel instantiations (launches x stand-alone ms): "
+                   + ", ".join(f"{k.split('<')[0]}<{k.split(', ', 1)[1]} {100 * v / fwd_ms:.1f}%" for k, v in sorted(share.items(), key=lambda kv: -kv[1])),
+            "achieved": round(avg_flops / avg_ms / 1e9, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(avg_flops / avg_ms / 1e9 / PEAK_MFMA_TFLOPS, 4),
+            "flops_per_launch": avg_flops, "ms_per_launch": round(avg_ms, 4), "launches_per_forward": n_calls,
+            "in_forward_ms_per_launch": round(sum(x * r["calls"] for x, r in zip(infw, members)) / n_calls, 4) if all(infw) else None,
+            "traffic": round(sum(x * r["calls"] for x, r in zip(tr, members)) / n_calls) if all(tr) else None,
+            "algorithmic_bytes_per_launch": round(sum(r["bytes"] * r["calls"] for r in members) / n_calls),
+            "traffic_source": traffic_src,
+            "timed": "per-launch averages over the instantiation's launches in one forward; each member: HIP events around 20 back-to-back "
+                     "launches, median of 3 rounds interleaved with the other per-layer kernels, after 10 warm-up launches; in_forward: an "
+                     "event pair per launch inside 5 forwards of the timed workload (adds ~10-20 us of event latency per pair)",
+            "members": mem}
+        # the other per-layer kernels, priced the same way (the MFMA-bound consumers, the HBM-bound attention)
+        others = []
+        for r in rows:
+            if r["inst"] and r["calls"] and r["inst"] != dom:
+                t_mfma, t_hbm = r["flops"] / (PEAK_MFMA_TFLOPS * 1e9), r["bytes"] / (PEAK_HBM_GBPS * 1e6)
+                hb = t_hbm > t_mfma
+                others.append({"kernel": r["kernel"], "inst": r["inst"], "bound": "hbm" if hb else "mfma", "ms_per_launch": r["ms"],
+                               "frac": round((r["bytes"] / r["ms"] / 1e6 / PEAK_HBM_GBPS) if hb else (r["flops"] / r["ms"] / 1e9 / PEAK_MFMA_TFLOPS), 4),
+                               "share_of_forward": round(r["ms"] * r["calls"] / fwd_ms, 4), "traffic": traffic_of(r["key"]),
+                               "algorithmic_bytes_per_launch": r["bytes"]})
+        out["roofline_other_kernels"] = others
     if solo and not a.no_kernels:
         # yardstick, not a target: the vendor library (torch.matmul -> hipBLASLt) on the roofline kernel's shape, plain
         # GEMM with 16-bit output and NO bias / QuickGELU epilogue

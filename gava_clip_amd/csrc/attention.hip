@@ -655,7 +655,105 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
   return GAVA_OK;
 }
 
+// Exact-fp32 attention for short sequences (gava_attention_f32): one workgroup per (sequence, head), thread t owns query t.
+// K and V of the head sit in LDS as fp32; every thread walks the keys in the same order, so each LDS read is a broadcast.
+// Two passes over the keys (row max, then exp / sum / P.V): no rescaling, scores recomputed (64 FMAs) instead of kept.
+template <class P>
+__global__ __launch_bounds__(128) void attention_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, long ld, unsigned short* out, long ldo,
+                                                            int heads, int L, int causal, int split, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float kv[];   // [2][L][64]
+  float* Ks = kv;
+  float* Vs = kv + (size_t)L * 64;
+  const int n = blockIdx.x / heads, h = blockIdx.x - n * heads;
+  const int t = threadIdx.x;
+  for (int i = t; i < L * 16; i += blockDim.x) {
+    const int row = i >> 4, c = (i & 15) * 4;
+    const long off = ((long)n * L + row) * ld + h * 64 + c;
+    *reinterpret_cast<float4*>(Ks + row * 64 + c) = *reinterpret_cast<const float4*>(k + off);
+    *reinterpret_cast<float4*>(Vs + row * 64 + c) = *reinterpret_cast<const float4*>(v + off);
+  }
+  float qr[64];
+  const int tq = t < L ? t : L - 1;
+#pragma unroll
+  for (int c = 0; c < 64; c += 4) {
+    const float4 x = *reinterpret_cast<const float4*>(q + ((long)n * L + tq) * ld + h * 64 + c);
+    qr[c] = x.x * scale; qr[c + 1] = x.y * scale; qr[c + 2] = x.z * scale; qr[c + 3] = x.w * scale;
+  }
+  __syncthreads();
+  const int lim = causal ? tq : L - 1;                                     // last key this query sees
+  const int kend = causal ? min(L, ((t >> 6) + 1) * 64) : L;              // wave-uniform loop bound
+  auto dot = [&](int key) {
+    const float4* kr = reinterpret_cast<const float4*>(Ks + key * 64);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float4 x = kr[c];
+      s0 = fmaf(qr[4 * c], x.x, s0); s1 = fmaf(qr[4 * c + 1], x.y, s1);
+      s2 = fmaf(qr[4 * c + 2], x.z, s2); s3 = fmaf(qr[4 * c + 3], x.w, s3);
+    }
+    return (s0 + s1) + (s2 + s3);
+  };
+  float mx = -INFINITY;
+  for (int key = 0; key < kend; ++key) {
+    const float sc = dot(key);
+    mx = key <= lim ? fmaxf(mx, sc) : mx;
+  }
+  float o[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) o[c] = 0.f;
+  float sum = 0.f;
+  for (int key = 0; key < kend; ++key) {
+    const float sc = dot(key);
+    const float pr = key <= lim ? __builtin_amdgcn_exp2f((sc - mx) * LOG2E) : 0.f;
+    sum += pr;
+    const float4* vr = reinterpret_cast<const float4*>(Vs + key * 64);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float4 x = vr[c];
+      o[4 * c] = fmaf(pr, x.x, o[4 * c]); o[4 * c + 1] = fmaf(pr, x.y, o[4 * c + 1]);
+      o[4 * c + 2] = fmaf(pr, x.z, o[4 * c + 2]); o[4 * c + 3] = fmaf(pr, x.w, o[4 * c + 3]);
+    }
+  }
+  if (t >= L) return;
+  const float inv = 1.0f / sum;
+  unsigned short* op = out + ((long)n * L + t) * ldo + h * 64;
+  const int Dm = heads * 64;
+#pragma unroll
+  for (int c = 0; c < 64; c += 4) {
+    if (split) {
+      uint2 hi, lo;
+      split4<P>(o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv, hi, lo);
+      *reinterpret_cast<uint2*>(op + c) = hi;
+      *reinterpret_cast<uint2*>(op + c + Dm) = lo;
+      *reinterpret_cast<uint2*>(op + c + 2 * Dm) = hi;
+    } else {
+      *reinterpret_cast<uint2*>(op + c) = pack4<P>(o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv);
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int gava_attention_f32(const gava_attention_f32_args* a, gava_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->v || !a->out) return GAVA_EINVAL;
+  if (a->batch <= 0 || a->heads <= 0 || a->L <= 0 || a->L > 128) return GAVA_EINVAL;
+  if (a->ld % 4 || a->ld_out % 4 || a->ld < (int64_t)a->heads * 64) return GAVA_EINVAL;
+  if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15 || ((uintptr_t)a->out & 7)) return GAVA_EINVAL;
+  if (a->ld_out < (a->split_out ? 3 : 1) * (int64_t)a->heads * 64) return GAVA_EINVAL;
+  const size_t lds = (size_t)2 * a->L * 64 * sizeof(float);
+  const dim3 grid(a->batch * a->heads), blk(a->L <= 64 ? 64 : 128);
+  hipStream_t s = (hipStream_t)stream;
+  if (a->prec == GAVA_PREC_F16)
+    hipLaunchKernelGGL((attention_f32_kernel<PrecF16>), grid, blk, lds, s, a->q, a->k, a->v, (long)a->ld, (unsigned short*)a->out,
+                       (long)a->ld_out, a->heads, a->L, a->causal, a->split_out, a->scale);
+  else if (a->prec == GAVA_PREC_BF16)
+    hipLaunchKernelGGL((attention_f32_kernel<PrecBF16>), grid, blk, lds, s, a->q, a->k, a->v, (long)a->ld, (unsigned short*)a->out,
+                       (long)a->ld_out, a->heads, a->L, a->causal, a->split_out, a->scale);
+  else return GAVA_EINVAL;
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
 
 extern "C" int gava_attention(const gava_attention_args* a, gava_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->out) return GAVA_EINVAL;

@@ -36,8 +36,10 @@ struct SideStream {
 // fc1 probe (gava_probe_fc1_enable / _read): event pairs around the roofline kernel inside the forward
 struct Fc1Probe {
   hipEvent_t ev[64][2];
-  bool made = false, on = false;
+  bool made = false;
+  int on = 0;     // 0 = off, else which kernel of a block is bracketed (GAVA_PROBE_* in gava_hip.h)
   int n = 0;
+  unsigned long long valid = 0;   // block slots whose pair was recorded by the last forward
   bool ensure() {
     if (made) return true;
     for (int i = 0; i < 64; ++i)
@@ -208,15 +210,18 @@ extern "C" int gava_abi_version(void) { return (int)(GAVA_ABI_HASH); }
 
 extern "C" int gava_probe_fc1_enable(int on) {
   Fc1Probe& g_probe = device_ctx().probe;
-  g_probe.on = on != 0; if (!on) g_probe.n = 0; return GAVA_OK;
+  if (on < 0 || on > GAVA_PROBE_ATTN) return GAVA_EINVAL;
+  g_probe.on = on; if (!on) g_probe.n = 0; return GAVA_OK;
 }
 extern "C" int gava_probe_fc1_read(float* ms, int cap) {
   Fc1Probe& g_probe = device_ctx().probe;
   const int n = g_probe.n;
   if (n <= 0 || !ms) return 0;
   if (hipEventSynchronize(g_probe.ev[n - 1][1]) != hipSuccess) return 0;
-  for (int i = 0; i < n && i < cap; ++i)
-    if (hipEventElapsedTime(&ms[i], g_probe.ev[i][0], g_probe.ev[i][1]) != hipSuccess) return 0;
+  for (int i = 0; i < n && i < cap; ++i) {
+    ms[i] = -1.0f;    // a block the probed kernel did not run in
+    if (((g_probe.valid >> i) & 1) && hipEventElapsedTime(&ms[i], g_probe.ev[i][0], g_probe.ev[i][1]) != hipSuccess) return 0;
+  }
   return n;
 }
 
@@ -285,8 +290,15 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
 
   // ---- blocks (VitaCLIP_vision_encoder.py:115-121, VitaCLIP_vision_encoder_utils.py:155-203)
   bool folded_in = false;   // Xn / STATS already hold this block's un-normalised input and its row statistics
-  const bool probe = g_probe.on && m->layers <= 64 && g_probe.ensure();
-  if (probe) g_probe.n = 0;
+  const int probe = (g_probe.on && m->layers <= 64 && g_probe.ensure()) ? g_probe.on : 0;
+  if (probe) { g_probe.n = 0; g_probe.valid = 0; }
+  // event pair k (0 = before, 1 = after) of block i around the kernel the probe names
+  auto mark = [&](int which, int i, int k) -> int {
+    if (probe != which) return GAVA_OK;
+    if (hipEventRecord(g_probe.ev[i][k], s) != hipSuccess) return GAVA_ELAUNCH;
+    if (k == 1) { g_probe.n = i + 1; g_probe.valid |= 1ull << i; }
+    return GAVA_OK;
+  };
   for (int i = 0; i < m->layers; ++i) {
     const gava_vision_layer& L = m->layer[i];
     TRY(keep(1 + i));
@@ -338,11 +350,13 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
     if (!fold1 && !(i == 0 && pre_fused)) TRY(ln(w.X, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
     const unsigned short* sk = (const unsigned short*)w.SIDEKV;
     if (not_last) {
+      if (fold1) TRY(mark(GAVA_PROBE_QKV, i, 0));     // the folded form only: the instantiation bench.py's table names
       if (fold1) {
         Fold c = consume(L.qkv_fold_s, L.qkv_fold_t);
         TRY(gemm(w.Xn, D, L.w_qkv_fold, D, nullptr, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, &c, resv));
       } else
       TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, nullptr, resv));
+      if (fold1) TRY(mark(GAVA_PROBE_QKV, i, 1));
       if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
       {
         gava_attention_args a{};
@@ -352,28 +366,35 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
         a.out = w.MIX; a.ld_out = D;
         a.batch = BT; a.heads = m->H; a.n_q = n + 1; a.n_kmain = n + 1;
         a.n_g = G; a.T = Tm; a.has_summary = 1; a.prec = pr;
+        TRY(mark(GAVA_PROBE_ATTN, i, 0));
         if (!skip_attn) TRY(gava_attention(&a, stream));
+        TRY(mark(GAVA_PROBE_ATTN, i, 1));
       }
+      TRY(mark(GAVA_PROBE_OUT, i, 0));
       if (fold2) {
         TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
+        TRY(mark(GAVA_PROBE_OUT, i, 1));
         if (!skip_stats && !fused) TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
         Fold c = consume(L.fc1_fold_s, L.fc1_fold_t);
-        if (probe && hipEventRecord(g_probe.ev[i][0], s) != hipSuccess) return GAVA_ELAUNCH;
+        TRY(mark(GAVA_PROBE_FC1, i, 0));
         TRY(gemm(w.Xn, D, L.w_fc1_fold, D, nullptr, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, &c));
-        if (probe && hipEventRecord(g_probe.ev[i][1], s) != hipSuccess) return GAVA_ELAUNCH;
+        TRY(mark(GAVA_PROBE_FC1, i, 1));
       } else {
         TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D));
+        TRY(mark(GAVA_PROBE_OUT, i, 1));
         TRY(ln(w.X, D, nullptr, L.ln2_g, L.ln2_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
-        if (probe && hipEventRecord(g_probe.ev[i][0], s) != hipSuccess) return GAVA_ELAUNCH;
+        TRY(mark(GAVA_PROBE_FC1, i, 0));
         TRY(gemm(w.Xn, D, L.w_fc1, D, L.b_fc1, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream));
-        if (probe && hipEventRecord(g_probe.ev[i][1], s) != hipSuccess) return GAVA_ELAUNCH;
+        TRY(mark(GAVA_PROBE_FC1, i, 1));
       }
-      if (probe) g_probe.n = i + 1;
+      TRY(mark(GAVA_PROBE_FC2, i, 0));
       if (fold1_next) {
         TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
+        TRY(mark(GAVA_PROBE_FC2, i, 1));
         if (!skip_stats && !fused) TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
       } else {
         TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D));
+        TRY(mark(GAVA_PROBE_FC2, i, 1));
       }
       folded_in = fold1_next;
     } else {
@@ -591,7 +612,9 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
 
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct TextWs { float* X; void* Xn; void* QKV; void* MIX; void* HID; void* EOT16; size_t total; };
+struct TextWs { float* X; void* Xn; void* QKV; void* MIX; void* HID; void* EOT16; float* QKV32; size_t total; };
+// fp32 q/k/v + fp32 softmax core (gava_text_model.attn_f32): inference with split-precision GEMMs and a short sequence
+bool text_attn_f32(const gava_text_model* m) { return m->attn_f32 && m->split && m->L <= 128; }
 
 TextWs carve_text(const gava_text_model* m, void* ws, size_t cap) {
   const long R = (long)m->n_prompts * m->L, W = m->W, S = m->split ? 3 : 1;
@@ -603,6 +626,7 @@ TextWs carve_text(const gava_text_model* m, void* ws, size_t cap) {
   w.MIX = c.take(R * S * W * 2);
   w.HID = c.take(R * S * 4 * W * 2);
   w.EOT16 = c.take((long)m->n_prompts * S * W * 2);
+  w.QKV32 = text_attn_f32(m) ? (float*)c.take(R * 3 * W * 4) : nullptr;
   w.total = (c.off + 255) & ~(size_t)255;
   return w;
 }
@@ -639,6 +663,7 @@ extern "C" int gava_text_forward_train(const gava_text_model* m, const int32_t* 
   hipStream_t s = (hipStream_t)stream;
   const int R = m->n_prompts * m->L, W = m->W, pr = m->prec;
   const int sp = m->split ? 1 : 0, S = sp ? 3 : 1;  // split precision: A rows are [hi|lo|hi], K' = 3K
+  const bool f32_core = !saved_x && text_attn_f32(m);   // inference only: the backward recomputes blocks with the 16-bit core
   TRY(gava::text_embed(m->token_embedding, m->positional_embedding, ctx, tokens, w.X, m->n_prompts, m->L, W, m->n_ctx, s));
   auto keep = [&](int i) -> int {   // training: the input of block i (i == layers: the final stream)
     if (!saved_x) return GAVA_OK;
@@ -649,8 +674,16 @@ extern "C" int gava_text_forward_train(const gava_text_model* m, const int32_t* 
     const gava_text_layer& L = m->layer[i];
     TRY(keep(i));
     TRY(ln(w.X, W, nullptr, L.ln1_g, L.ln1_b, w.Xn, S * W, nullptr, 0, R, W, pr, stream, sp));
-    TRY(gemm(w.Xn, S * W, L.w_qkv, S * W, L.b_qkv, w.QKV, 3 * W, R, 3 * W, S * W, GAVA_EPI_H16, pr, stream, nullptr, 0, W, 0.125f));
-    {
+    if (f32_core) {
+      // q, k, v straight out of the split-precision GEMM in fp32, softmax core in fp32: nothing of the attention branch is
+      // rounded to 16 bits before the [hi | lo | hi] operand of the out-projection
+      TRY(gemm(w.Xn, S * W, L.w_qkv, S * W, L.b_qkv, w.QKV32, 3 * W, R, 3 * W, S * W, GAVA_EPI_F32, pr, stream));
+      gava_attention_f32_args a{};
+      a.q = w.QKV32; a.k = w.QKV32 + W; a.v = w.QKV32 + 2 * W; a.ld = 3 * W; a.out = w.MIX; a.ld_out = S * W;
+      a.batch = m->n_prompts; a.heads = m->H; a.L = m->L; a.causal = 1; a.prec = pr; a.split_out = sp; a.scale = 0.125f;
+      TRY(gava_attention_f32(&a, stream));
+    } else {
+      TRY(gemm(w.Xn, S * W, L.w_qkv, S * W, L.b_qkv, w.QKV, 3 * W, R, 3 * W, S * W, GAVA_EPI_H16, pr, stream, nullptr, 0, W, 0.125f));
       gava_attention_args a{};
       const unsigned short* q = (const unsigned short*)w.QKV;
       a.q = q; a.k = q + W; a.v = q + 2 * W; a.ld_qkv = 3 * W; a.out = w.MIX; a.ld_out = S * W;

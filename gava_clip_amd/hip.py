@@ -22,7 +22,7 @@ EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_text_forward", "gava_similarity_head", "gava_convert_h16", "gava_debug_set_buffer",
            "gava_preprocess_clip", "gava_layernorm_backward", "gava_qgelu_backward", "gava_attention_backward",
            "gava_text_forward_train", "gava_vision_forward_train", "gava_attention_backward_workspace_bytes", "gava_vision_forward_keep", "gava_row_stats",
-           "gava_probe_fc1_enable", "gava_probe_fc1_read", "gava_clip_geometry", "gava_patchify"]
+           "gava_probe_fc1_enable", "gava_probe_fc1_read", "gava_clip_geometry", "gava_patchify", "gava_attention_f32"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 
@@ -89,9 +89,15 @@ class TextLayer(C.Structure):
         "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
 
 
+class AttentionF32Args(C.Structure):
+    _fields_ = [("q", _fp), ("k", _fp), ("v", _fp), ("ld", C.c_int64), ("out", _vp), ("ld_out", C.c_int64),
+                ("batch", C.c_int), ("heads", C.c_int), ("L", C.c_int), ("causal", C.c_int), ("prec", C.c_int),
+                ("split_out", C.c_int), ("scale", C.c_float)]
+
+
 class TextModel(C.Structure):
     _fields_ = [("n_prompts", C.c_int), ("L", C.c_int), ("W", C.c_int), ("H", C.c_int), ("layers", C.c_int),
-                ("E", C.c_int), ("n_ctx", C.c_int), ("prec", C.c_int), ("split", C.c_int),
+                ("E", C.c_int), ("n_ctx", C.c_int), ("prec", C.c_int), ("split", C.c_int), ("attn_f32", C.c_int),
                 ("token_embedding", _fp), ("positional_embedding", _fp), ("lnf_g", _fp), ("lnf_b", _fp),
                 ("w_tproj", _vp), ("layer", C.POINTER(TextLayer))]
 
@@ -169,6 +175,7 @@ def load():
                        ("gava_attention", [C.POINTER(AttentionArgs), _vp])):
         f = getattr(lib, name)
         f.argtypes, f.restype = args, C.c_int
+    lib.gava_attention_f32.argtypes, lib.gava_attention_f32.restype = [C.POINTER(AttentionF32Args), _vp], C.c_int
     lib.gava_vision_workspace_bytes.argtypes = [C.POINTER(VisionModel)]
     lib.gava_vision_workspace_bytes.restype = C.c_size_t
     lib.gava_vision_forward.argtypes = [C.POINTER(VisionModel), _fp, _fp, _fp, _fp, _vp, C.c_size_t, _vp]
@@ -257,6 +264,14 @@ def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0
     a.pos, a.time, a.n_patches, a.T = ptr(pos), ptr(time), n_patches, T
     a.split_out = int(split_out)
     check(load().gava_gemm(C.byref(a), stream_ptr()), "gava_gemm")
+
+
+def attention_f32(q, k, v, out, *, batch, heads, L, prec, causal=False, split_out=False, scale=0.125):
+    a = AttentionF32Args()
+    a.q, a.k, a.v, a.ld = ptr(q), ptr(k), ptr(v), q.stride(0)
+    a.out, a.ld_out = ptr(out), out.stride(0)
+    a.batch, a.heads, a.L, a.causal, a.prec, a.split_out, a.scale = batch, heads, L, int(causal), prec, int(split_out), scale
+    check(load().gava_attention_f32(C.byref(a), stream_ptr()), "gava_attention_f32")
 
 
 def layernorm(x, gamma, beta, *, out16=None, out32=None, prec, rows=None, in_stride=None, row_index=None,

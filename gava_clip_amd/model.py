@@ -342,6 +342,9 @@ class _HipHost:
         # text tower GEMMs in split precision (hi+lo operands, 3 MFMA passes): the text side is <1 % of
         # the work at the headline configs but dominates the logits error at plain 16-bit operands
         self.text_split_precision = os.environ.get("GAVA_TEXT_SPLIT", "1") != "0"
+        # with it (inference): q/k/v leave their GEMM in fp32 and the softmax core runs in fp32 - the text features then carry
+        # no 16-bit rounding at all (GAVA_TEXT_ATTN_F32=0: the MFMA attention on 16-bit q/k/v, as in rounds 1-2)
+        self.text_attention_fp32 = os.environ.get("GAVA_TEXT_ATTN_F32", "1") != "0"
         # eval-time text-feature cache: in eval mode the text tower is input
         # independent; opt-in because a benchmark must not skip work.  Invalidated by any parameter update.
         self.cache_text_features = False
@@ -648,6 +651,7 @@ class _HipHost:
         m.n_prompts, m.L, m.W, m.H, m.layers = n, L, sh["W"], sh["TH"], sh["TL"]
         m.E, m.n_ctx, m.prec = sh["E"], n_ctx, self.prec
         m.split = int(self.text_split_precision)
+        m.attn_f32 = int(self.text_split_precision and self.text_attention_fp32)
         for k, val in pk["txt"].items():
             setattr(m, k, val)
         m.layer = C.cast(pk["txt_layers"], C.POINTER(hip.TextLayer))

@@ -46,9 +46,16 @@ int gava_abi_version(void);
 /* Debug hook: device buffer (u64[8] per wave) that instrumented kernels fill with per-segment cycle
  * sums; NULL (default) disables every stamp.  Not used by the product path. */
 int gava_debug_set_buffer(void* dev_u64);
-/* Measurement hook (bench.py `roofline`): while enabled, gava_vision_forward brackets the fc1 GEMM of every full-width
- * block with a pair of HIP events on the stream it launches on.  gava_probe_fc1_read waits for the last pair and returns
- * the number of pairs, writing up to `cap` elapsed times in ms.  Off by default; never enabled by the model code. */
+/* Measurement hook (bench.py `roofline`): while enabled, gava_vision_forward brackets ONE kernel of every full-width block
+ * with a pair of HIP events on the stream it launches on: on = GAVA_PROBE_FC1 (the fc1 GEMM), _OUT (out_proj), _FC2,
+ * _QKV (the LayerNorm-folded qkv GEMM: blocks 1 .. layers-2) or _ATTN; 0 = off.  gava_probe_fc1_read waits for the last
+ * pair and returns the number of block slots, writing up to `cap` elapsed times in ms (-1 in the slots of blocks the probed
+ * kernel did not run in: _QKV leaves slot 0 unused).  Off by default; never enabled by the model code. */
+#define GAVA_PROBE_FC1 1
+#define GAVA_PROBE_OUT 2
+#define GAVA_PROBE_FC2 3
+#define GAVA_PROBE_QKV 4
+#define GAVA_PROBE_ATTN 5
 int gava_probe_fc1_enable(int on);
 int gava_probe_fc1_read(float* ms, int cap);
 
@@ -178,6 +185,20 @@ typedef struct {
 } gava_attention_args;
 int gava_attention(const gava_attention_args* a, gava_stream_t stream);
 
+/* Exact-fp32 softmax attention for SHORT sequences (the text tower in inference: 77 padded tokens, 15-20 after the rows behind
+ * the EOT are trimmed): q, k, v fp32 rows [batch*L][ld] (head h = columns [64h, 64h+64)), scores = scale * q.k (+ causal
+ * mask), softmax and P.V in fp32 on the vector ALU - no 16-bit rounding of Q, K, V or P anywhere.  out: h16 rows
+ * [batch*L][ld_out]; split_out != 0 writes [hi | lo | hi] copies heads*64 columns apart (A operand of a split-precision
+ * GEMM, see gava_gemm_args.split_out).  Replaces the scaled-dot-product core of nn.MultiheadAttention
+ * (VitaCLIP_text_encoder.py:71,83) where 16-bit MFMA operands would set the error of the text features.  L <= 128. */
+typedef struct {
+  const float* q; const float* k; const float* v; int64_t ld;
+  void* out; int64_t ld_out;
+  int batch, heads, L, causal, prec, split_out;
+  float scale;
+} gava_attention_f32_args;
+int gava_attention_f32(const gava_attention_f32_args* a, gava_stream_t stream);
+
 /* ---- fused drivers ---------------------------------------------------------------------- */
 
 typedef struct {                 /* one TransformerEncoderLayer, utils:93-203 */
@@ -240,6 +261,8 @@ typedef struct {
   int n_prompts, L, W, H, layers, E, n_ctx, prec;
   int split;                               /* 1: split-precision GEMMs; every weight below is then
                                               packed [W_hi | W_hi | W_lo] with 3x the columns    */
+  int attn_f32;                            /* with split, inference, L <= 128: q/k/v leave their GEMM in fp32 and the
+                                              attention core runs in fp32 (gava_attention_f32)  */
   const float* token_embedding;            /* [vocab][W] fp32                                */
   const float* positional_embedding;       /* [L][W]                                         */
   const float* lnf_g; const float* lnf_b;

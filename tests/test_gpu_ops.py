@@ -522,3 +522,33 @@ def test_gemm_named_kernel_rejects_what_it_does_not_take():
                  epilogue=hip.EPI_H16, prec=hip.PREC_F16, kernel=hip.KERNEL_PAIR)
     with pytest.raises(hip.GavaError):       # unknown kernel id
         hip.gemm(A, W, None, torch.zeros(300, 256, device=d), epilogue=hip.EPI_F32, prec=hip.PREC_F16, kernel=9)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("batch,heads,L,causal,split", [(3, 8, 77, True, True), (5, 2, 17, True, False), (2, 12, 128, False, True),
+                                                      (400, 8, 19, True, True), (1, 1, 1, True, False)])
+def test_attention_f32_core(prec, batch, heads, L, causal, split):
+    """gava_attention_f32 (the text tower's softmax core in inference): fp32 q/k/v in, scores / softmax / P.V in fp32, only
+    the output is rounded - to 16 bits, or to a [hi | lo | hi] pair whose hi + lo carries ~22 bits."""
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    Wd = heads * 64
+    qkv = rnd((batch * L, 3 * Wd), 1.0, 11).to(d)
+    S = 3 if split else 1
+    out = torch.zeros(batch * L, S * Wd, dtype=dt, device=d)
+    hip.attention_f32(qkv[:, :Wd], qkv[:, Wd:2 * Wd], qkv[:, 2 * Wd:], out, batch=batch, heads=heads, L=L, prec=prec,
+                      causal=causal, split_out=split, scale=0.125)
+    q, k, v = (qkv[:, i * Wd:(i + 1) * Wd].reshape(batch, L, heads, 64).permute(0, 2, 1, 3).double() for i in range(3))
+    sc = (q * 0.125) @ k.transpose(-1, -2)
+    if causal:
+        sc = sc + torch.full((L, L), float("-inf"), device=d, dtype=torch.float64).triu(1)
+    ref = (sc.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(batch * L, Wd)
+    if split:
+        hi, lo = out[:, :Wd].double(), out[:, Wd:2 * Wd].double()
+        assert torch.equal(out[:, :Wd], out[:, 2 * Wd:])
+        got, tol = hi + lo, 4 * EPS16[prec] ** 2 + 2e-6          # two 16-bit words: the error is fp32's
+    else:
+        got, tol = out.double(), 2 * EPS16[prec]
+    assert float((got - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    with pytest.raises(hip.GavaError):
+        hip.attention_f32(qkv[:, :Wd], qkv[:, Wd:2 * Wd], qkv[:, 2 * Wd:], out, batch=1, heads=heads, L=129, prec=prec)
