@@ -134,11 +134,19 @@ struct VisionWs {
 
 int patch_k(const gava_vision_model* m) { return (3 * m->P * m->P + 63) / 64 * 64; }
 
-// The A operand of the patch-embedding GEMM: the 16-bit patch matrix written into `scratch` (gava_patchify), or, with
-// GAVA_PATCH_DIRECT=1, the frames themselves for the GEMM's in-loop loaders.
+// The A operand of the patch-embedding GEMM.
+//   fp32 clips (the reference's input, the benchmark's): IM2COL-FREE - the GEMM builds its A tiles in the k-loop straight from
+//   the NCTHW frames (two coalesced float4 loads per 8 k-values, converted and written to the LDS stage: gemm_kernel's
+//   patch_load / patch_write); no patch matrix exists.  0.352 ms vs 0.343 ms for the two-pass form at c2 (inside box noise).
+//   decoded uint8 videos (forward_frames): two passes - gava_patchify writes the 16-bit patch matrix once (0.46 ms: every
+//   element is a bilinear sample, 4 byte loads + the lerp), the GEMM stages it by LDS-DMA (0.26 ms).  Built inside the k-loop
+//   the same samples are recomputed for each of the three 256-column tiles and cannot hide behind 0.23 GF of MFMA work per
+//   frame: 2.33 ms.  GAVA_PATCH_DIRECT=0 / 1 forces the two-pass / the in-loop form for either source (A/B, op tests).
 int patch_operand(const gava_vision_model* m, const float* x, void* scratch, int Kp, int prec, gava_stream_t stream,
                   gava_gemm_args* a) {
-  static const bool direct = getenv("GAVA_PATCH_DIRECT") != nullptr;
+  static const int forced = getenv("GAVA_PATCH_DIRECT") ? atoi(getenv("GAVA_PATCH_DIRECT")) : -1;
+  // (P % 8 != 0 - ViT-L/14 - has no float4 form of the in-loop loader: eight scalar loads per chunk; it stays two-pass)
+  const bool direct = forced >= 0 ? forced != 0 : (m->clips == nullptr && m->P % 8 == 0);
   a->lda = Kp; a->frame_size = m->size; a->patch = m->P;
   if (direct) {
     a->A = nullptr; a->frames = m->clips ? nullptr : x; a->clips = m->clips; a->clip_lut = m->clip_lut;
@@ -255,10 +263,7 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
 
   // ---- embedding (VitaCLIP_vision_encoder.py:105-113)
   {
-    // patch matrix in 16 bits first (one HBM-bound pass, parked in the still unused fc1 buffer), then a GEMM that stages it
-    // by LDS-DMA like every other operand: 0.25 ms instead of 0.38 ms for the loader that converted fp32 frames inside the
-    // k-loop, and 0.3 ms instead of 2.3 ms for the uint8 source (tools/kernel_bench.py patch / patchA / patchu8).
-    // GAVA_PATCH_DIRECT=1 keeps the in-loop loaders (A/B, and the op tests still cover them).
+    // im2col-free for fp32 clips, patch matrix + LDS-DMA GEMM for decoded uint8 videos: see patch_operand
     gava_gemm_args a{};
     TRY(patch_operand(m, x, w.HID, Kp, pr, stream, &a));
     a.W = m->w_patch; a.ldw = Kp; a.bias = m->b_patch;
