@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-3 evidence bundle, part B: rocprofv3 kernel summaries of the bench command (c2, c3, c5), PMC passes of the five
+# per-layer kernels in the form the forward launches them -> traffic.json, board power / clock while the forward loops.
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r3final; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+for cfg in c2 c3 c5; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$cfg -o x -- python3 $R/bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline --no-alt --no-kernels --no-train --no-accuracy > $O/prof_$cfg.log 2>&1 || tail -5 $O/prof_$cfg.log
+  S=$(find $O/prof_$cfg -name "*kernel_stats.csv" | head -1); cp $S $O/bench_${cfg}_kernel_stats.csv
+  T=$(find $O/prof_$cfg -name "*kernel_trace.csv" | head -1); python3 $R/tools/trace_gaps.py $T > $O/gaps_$cfg.txt 2>&1
+  rm -rf $O/prof_$cfg
+  head -4 $O/bench_${cfg}_kernel_stats.csv | cut -c1-160
+done
+cd $R
+for k in fc1part qkvpart outpart fc2part attn; do
+  bash tools/pmc.sh r3_$k $k --iters 3 > $O/pmc_$k.txt 2>&1
+  rm -rf $R/gpurun_out/pmc_r3_$k
+  echo "== $k"; grep -E "^void|^\(anon|FETCH_SIZE|WRITE_SIZE|TCC_HIT|TCC_MISS" $O/pmc_$k.txt | cut -c1-110
+done
+python3 tools/make_traffic.py $O $O/traffic.json > /dev/null && head -c 600 $O/traffic.json
+( python3 - <<PY
+import sys, os, torch
+sys.path.insert(0, "$R"); sys.path.insert(0, "$R/tests")
+import gava_clip_amd.config as C
+from gava_clip_amd import VitaCLIP
+from helpers import model_kwargs
+m = VitaCLIP(**model_kwargs(C.VIT_B16_T8, "$R/gava_clip_amd/data/classes/updrs_3cls_classes.txt")).cuda().eval()
+x = torch.randn(64, 3, 8, 224, 224, device="cuda")
+with torch.no_grad():
+    for _ in range(400): m(x)
+torch.cuda.synchronize()
+PY
+) &
+LOOP=$!
+sleep 6
+for i in $(seq 1 16); do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Socket Power|sclk" | tr '\n' ' '; echo; sleep 0.25; done > $O/power_watch.txt
+wait $LOOP
+head -4 $O/power_watch.txt
