@@ -659,6 +659,14 @@ void gemm256_kernel(const GemmParams p) {
   // Static priority for the second-dispatched half: at equal priority waves 4-7 lose every issue arbitration to
   // their older SIMD partners and trail them by ~800 cycles per stage (stamps: stage 4.6k -> 4.1k cycles).
   if (GAVA_V3_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#ifdef GAVA_EXP_STAGGER   // experiment builds (-DGAVA_EXP_STAGGER, nothing inside the loops): a start offset between workgroups,
+  {                       // GAVA_PAIR_DELAY x 10 ns; GAVA_STAGGER_MODE 0: odd slots of every XCD late, 1: (slot & 3) * delay / 2, 2: XCDs 4-7 late
+    const unsigned long long d = p.pair_sleep == 1 ? (unsigned long long)(slot & 3) * p.pair_delay / 2
+                               : p.pair_sleep == 2 ? (xcd >= 4 ? p.pair_delay : 0) : ((slot & 1) ? p.pair_delay : 0);
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
 
   for (int j = 0; j < my_tiles; ++j) {
     for (int kt = 0; kt < nk; ++kt) {
@@ -1399,6 +1407,11 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.ablate = ablate;
 #else
   gp.ablate = 0;
+#endif
+#ifdef GAVA_EXP_STAGGER
+  static const int pdelay_ = getenv("GAVA_PAIR_DELAY") ? atoi(getenv("GAVA_PAIR_DELAY")) : 0;
+  static const int smode_ = getenv("GAVA_STAGGER_MODE") ? atoi(getenv("GAVA_STAGGER_MODE")) : 0;
+  gp.pair_delay = pdelay_; gp.pair_sleep = smode_;
 #endif
   gp.dbg = gava::debug_buffer();
   hipStream_t s = (hipStream_t)stream;
