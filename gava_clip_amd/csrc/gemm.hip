@@ -679,6 +679,9 @@ void gemm256_kernel(const GemmParams p) {
       if (stamp) { const unsigned long long t = clock64(); tW += t - ts; ts = t; }
       __builtin_amdgcn_s_barrier();
       if (stamp) { const unsigned long long t = clock64(); tB += t - ts; ts = t; }
+#ifdef GAVA_TIMELINE   // diagnostic builds (tools/gemm_timeline.py): 10 ns wall-clock stamps per tile from waves 0 and 4
+      if (kt == 0 && p.dbg && lane == 0 && (wave & 3) == 0 && j < 10) p.dbg[((size_t)blockIdx.x * 2 + (wave >> 2)) * 32 + j * 3 + 0] = wall_clock64();
+#endif
       // every wave has left the previous tile's epilogue: its row-sum partials are complete in LDS
       if (X16_STAGE && p.rowsum_reduced && kt == 0 && j > 0) flush_rowsum(m0p, n0p);
       // LDS-DMA issue is expensive (~100+ cycles per 1 KiB piece beside running MFMAs): the two waves
@@ -744,6 +747,9 @@ void gemm256_kernel(const GemmParams p) {
     }
 
     if (stamp) { const unsigned long long t = clock64(); tC += t - ts; ts = t; in_epi = true; }
+#ifdef GAVA_TIMELINE
+    if (p.dbg && lane == 0 && (wave & 3) == 0 && j < 10) p.dbg[((size_t)blockIdx.x * 2 + (wave >> 2)) * 32 + j * 3 + 1] = wall_clock64();
+#endif
     // ---- epilogue of tile j: lane holds out[m][n .. n+15], m = m0+wr*128+i*16+fr,
     //      n = n0 + wc*64 + 16*fg + 4*jj + r
     const int nb0 = n0 + wc * 64 + CF * fg;
@@ -922,6 +928,9 @@ void gemm256_kernel(const GemmParams p) {
       }
     }
     if (stamp) { const unsigned long long t = clock64(); tE2 += t - te; }
+#ifdef GAVA_TIMELINE
+    if (p.dbg && lane == 0 && (wave & 3) == 0 && j < 10) p.dbg[((size_t)blockIdx.x * 2 + (wave >> 2)) * 32 + j * 3 + 2] = wall_clock64();
+#endif
     if (CAN_FOLD && j + 1 < my_tiles) {
       // the next tile's fold block was issued before this epilogue's stores: it has landed once at most those are in flight
       // (partials mode: it landed, and was reduced, two stages ago)
@@ -942,6 +951,10 @@ void gemm256_kernel(const GemmParams p) {
     __syncthreads();
     flush_rowsum(m0p, n0p);
   }
+#ifdef GAVA_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (p.dbg && lane == 0 && (wave & 3) == 0) { p.dbg[((size_t)blockIdx.x * 2 + (wave >> 2)) * 32 + 30] = wall_clock64(); p.dbg[((size_t)blockIdx.x * 2 + (wave >> 2)) * 32 + 31] = my_tiles; }
+#endif
   if (stamp && lane == 0) {
     const unsigned long long t = clock64();
     tE += t - ts;
