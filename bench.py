@@ -385,7 +385,8 @@ def main():
         "config": {"workload": f"{a.config}: {desc}", "clips_per_gpu": B, "global_batch": B * world,
                    "frames": cfg.num_frames, "classes": n_cls, "weights": "random-init",
                    "parallelism": f"clips sharded over {world} GPU(s); RCCL all-gather of (B,E) embeddings" if world > 1 else "single GPU",
-                   "text_tower": "split-precision (3 MFMA passes)" if model.text_split_precision else a.prec},
+                   "text_tower": ("split-precision GEMMs (3 MFMA passes)" + (", fp32 softmax core" if getattr(model, "text_attention_fp32", False) else ""))
+                                 if model.text_split_precision else a.prec},
         # two FLOP figures: the REFERENCE's dense work for this batch (what a drop-in replaces; includes rows
         # whose results the reference discards) and the work this path EXECUTES (flops.executed_flops: no prompt-row
         # q/out/MLP, CLS-only last block, text rows up to the last EOT).  Utilisation is quoted on the executed figure.
