@@ -172,3 +172,39 @@ def test_forward_under_autocast_like_train_py(golden_dir):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         ev = m(x)[0]
     assert rel_to_max(ev.float().cpu().numpy(), g["logits"]) < 1e-3
+
+
+def test_text_tower_fp32_core_on_and_off_and_the_forward_probe(golden_dir):
+    """Round 3: (1) the text tower's fp32 softmax core (default) and the 16-bit MFMA core both meet the reference's text
+    features, the fp32 one by two orders of magnitude more closely; (2) the measurement hook bench.py uses
+    (gava_probe_fc1_enable / _read) brackets each per-layer kernel it can name and leaves the results untouched."""
+    import ctypes as C
+    g = np.load(os.path.join(golden_dir, "tiny.npz"))
+    m = VitaCLIP(**model_kwargs(TINY, CLASSES_3))
+    m.load_state_dict(synth_torch_state(TINY, 3), strict=True)
+    m = m.cuda().eval()
+    x = _x()
+    with torch.no_grad():
+        assert m.text_attention_fp32
+        lg32 = m(x)[0].clone()
+        e32 = rel_to_max(m.text_features.cpu().numpy(), g["text_features"])
+        m.text_attention_fp32 = False
+        lg16 = m(x)[0].clone()
+        e16 = rel_to_max(m.text_features.cpu().numpy(), g["text_features"])
+        m.text_attention_fp32 = True
+    print(f"\n[tiny] text features vs reference: fp32 core {e32:.2e}, 16-bit core {e16:.2e}")
+    assert e32 < 2e-5 and e16 < 2e-3 and e32 < e16
+    assert rel_to_max(lg32.cpu().numpy(), g["logits"]) < 1e-3 and rel_to_max(lg16.cpu().numpy(), g["logits"]) < 1e-3
+    lib = hip.load()
+    buf = (C.c_float * 64)()
+    try:
+        for which in (1, 2, 3, 5):               # fc1, out_proj, fc2, attention: every full-width block (all but the last)
+            assert lib.gava_probe_fc1_enable(which) == 0
+            with torch.no_grad():
+                lg = m(x)[0]
+            n = lib.gava_probe_fc1_read(buf, 64)
+            assert n == TINY.num_layers - 1 and all(0.0 < buf[i] < 50.0 for i in range(n)), (which, n, list(buf[:n]))
+            assert torch.equal(lg, lg32)
+        assert lib.gava_probe_fc1_enable(99) != 0
+    finally:
+        lib.gava_probe_fc1_enable(0)
