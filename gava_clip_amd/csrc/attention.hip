@@ -137,7 +137,9 @@ __device__ __forceinline__ FragAddr frag_addr(int fr, int fg) {
 // reciprocal row sums; the caller stores (pair_store) - the persistent kernel waits for its prefetch in between.
 // FULL: leading key tiles the dispatcher guarantees to hold only valid keys (no mask code for them at all); PCH: 32-key
 // chunks of V in flight per batch (registers).
-template <class P, int NKT, int FULL, int PCH = (NKT > 14 ? 2 : 4)>
+// DUAL = false: the second tile of the pair does not exist (an odd number of query tiles: ViT-L/14's 257 queries are 16 full
+// tiles + 1 query) - every MFMA, exp and pack of the b half is left out; same registers, a little more than half the work.
+template <class P, int NKT, int FULL, int PCH = (NKT > 14 ? 2 : 4), bool DUAL = true>
 __device__ __forceinline__ void pair_compute(const AttnParams& p, const char* ks, const char* vs, const FragAddr& fa, int fg,
                                              s16x8_t q0, s16x8_t q1, s16x8_t qb0, s16x8_t qb1,
                                              f32x4_t (&oa)[4], f32x4_t (&ob)[4], float& inva, float& invb,
@@ -166,14 +168,14 @@ __device__ __forceinline__ void pair_compute(const AttnParams& p, const char* ks
     for (int t = 0; t < QCH; ++t) {
       f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f}, b = a;
       a = P::mfma(kf[t][0], q0, a);
-      b = P::mfma(kf[t][0], qb0, b);
+      if (DUAL) b = P::mfma(kf[t][0], qb0, b);
       a = P::mfma(kf[t][1], q1, a);
-      b = P::mfma(kf[t][1], qb1, b);
+      if (DUAL) b = P::mfma(kf[t][1], qb1, b);
       sa[c0 + t] = a;
       sb[c0 + t] = b;
     }
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * QCH, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * QCH, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, (DUAL ? 4 : 2) * QCH, 0);
   }
   ATTN_STAMP(1, sb[NKT - 1]);
   // Invalid keys (rows past n_keys, staged as copies of row 0) get -inf: unconditionally on the tiles that may hold one -
@@ -188,13 +190,14 @@ __device__ __forceinline__ void pair_compute(const AttnParams& p, const char* ks
       for (int r = 0; r < 4; ++r) {
         const bool ok = kt * 16 + lane_key + r < p.n_keys;
         sa[kt][r] = ok ? sa[kt][r] : -INFINITY;
-        sb[kt][r] = ok ? sb[kt][r] : -INFINITY;
+        if (DUAL) sb[kt][r] = ok ? sb[kt][r] : -INFINITY;
       }
     }
     mxa = fmaxf(fmaxf(mxa, sa[kt][0]), fmaxf(sa[kt][1], fmaxf(sa[kt][2], sa[kt][3])));
-    mxb = fmaxf(fmaxf(mxb, sb[kt][0]), fmaxf(sb[kt][1], fmaxf(sb[kt][2], sb[kt][3])));
+    if (DUAL) mxb = fmaxf(fmaxf(mxb, sb[kt][0]), fmaxf(sb[kt][1], fmaxf(sb[kt][2], sb[kt][3])));
   }
-  mxa = max_across_lane_groups(mxa); mxb = max_across_lane_groups(mxb);
+  mxa = max_across_lane_groups(mxa);
+  if (DUAL) mxb = max_across_lane_groups(mxb);
   const float mna = -mxa * LOG2E, mnb = -mxb * LOG2E;
   ATTN_STAMP(2, mnb);
   float suma = 0.f, sumb = 0.f;
@@ -203,8 +206,9 @@ __device__ __forceinline__ void pair_compute(const AttnParams& p, const char* ks
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float ea = __builtin_amdgcn_exp2f(fmaf(sa[kt][r], LOG2E, mna));
-      const float eb = __builtin_amdgcn_exp2f(fmaf(sb[kt][r], LOG2E, mnb));
-      sa[kt][r] = ea; sb[kt][r] = eb;
+      sa[kt][r] = ea;
+      float eb = 0.f;
+      if (DUAL) { eb = __builtin_amdgcn_exp2f(fmaf(sb[kt][r], LOG2E, mnb)); sb[kt][r] = eb; }
       if (!GAVA_ATTN_ONESUM) { suma += ea; sumb += eb; }
     }
 
@@ -239,19 +243,22 @@ __device__ __forceinline__ void pair_compute(const AttnParams& p, const char* ks
         const int cc = b0 + c;
         const uint2 la = pack4<P>(sa[2 * cc][0], sa[2 * cc][1], sa[2 * cc][2], sa[2 * cc][3]);
         const uint2 ha = pack4<P>(sa[2 * cc + 1][0], sa[2 * cc + 1][1], sa[2 * cc + 1][2], sa[2 * cc + 1][3]);
-        const uint2 lb = pack4<P>(sb[2 * cc][0], sb[2 * cc][1], sb[2 * cc][2], sb[2 * cc][3]);
-        const uint2 hb = pack4<P>(sb[2 * cc + 1][0], sb[2 * cc + 1][1], sb[2 * cc + 1][2], sb[2 * cc + 1][3]);
         const s16x8_t pfa = __builtin_bit_cast(s16x8_t, make_uint4(la.x, la.y, ha.x, ha.y));
-        const s16x8_t pfb = __builtin_bit_cast(s16x8_t, make_uint4(lb.x, lb.y, hb.x, hb.y));
+        s16x8_t pfb = pfa;
+        if (DUAL) {
+          const uint2 lb = pack4<P>(sb[2 * cc][0], sb[2 * cc][1], sb[2 * cc][2], sb[2 * cc][3]);
+          const uint2 hb = pack4<P>(sb[2 * cc + 1][0], sb[2 * cc + 1][1], sb[2 * cc + 1][2], sb[2 * cc + 1][3]);
+          pfb = __builtin_bit_cast(s16x8_t, make_uint4(lb.x, lb.y, hb.x, hb.y));
+        }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const s16x8_t vf = __builtin_shufflevector(t0[c][dt], t1[c][dt], 0, 1, 2, 3, 4, 5, 6, 7);
           oa[dt] = P::mfma(vf, pfa, oa[dt]);
-          ob[dt] = P::mfma(vf, pfb, ob[dt]);
+          if (DUAL) ob[dt] = P::mfma(vf, pfb, ob[dt]);
         }
         if (GAVA_ATTN_ONESUM) {
           osa = P::mfma(ones, pfa, osa);
-          osb = P::mfma(ones, pfb, osb);
+          if (DUAL) osb = P::mfma(ones, pfb, osb);
         }
       }
     }
@@ -262,7 +269,7 @@ __device__ __forceinline__ void pair_compute(const AttnParams& p, const char* ks
     suma = sum_across_lane_groups(suma);
     sumb = sum_across_lane_groups(sumb);
   }
-  inva = __builtin_amdgcn_rcpf(suma); invb = __builtin_amdgcn_rcpf(sumb);
+  inva = __builtin_amdgcn_rcpf(suma); invb = DUAL ? __builtin_amdgcn_rcpf(sumb) : 0.f;
   ATTN_STAMP(4, ob[3]);
 #undef ATTN_STAMP
 }
@@ -364,6 +371,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
         unsigned long long* d = p.dbg + 4096 * 16 + (size_t)(blockIdx.x * 4 + wave) * 4;
         for (int i = 0; i < 4; ++i) d[i] = st[i + 1] - st[i];
       }
+#elif defined(GAVA_ATTN_ODD_TILE)
+      // experiment build (tools/ab_build.sh odd -DGAVA_ATTN_ODD_TILE; profiles/r03_attention_c5.txt): an odd last tile
+      // (ViT-L/14: 17 tiles) runs the one-tile form of the same code.  5 % SLOWER at c5 (256 VGPRs + scratch with the second
+      // instantiation inlined), so the product build keeps the half-empty pair.
+      if (2 * pr + 1 < n_qt) pair_compute<P, NKT, FULL>(p, ks, vs, fa, fg, q0, q1, qb0, qb1, oa, ob, inva, invb);
+      else pair_compute<P, NKT, FULL, (NKT > 14 ? 2 : 4), false>(p, ks, vs, fa, fg, q0, q1, qb0, qb1, oa, ob, inva, invb);
 #else
       pair_compute<P, NKT, FULL>(p, ks, vs, fa, fg, q0, q1, qb0, qb1, oa, ob, inva, invb);
 #endif
