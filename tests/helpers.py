@@ -56,9 +56,19 @@ GOLDEN_LOGIT_CASES = {
     "c1_b16_s1": ("VIT_B16_T8", "3", 2, 1, 1235),
     "c1_b16_s2": ("VIT_B16_T8", "3", 2, 2, 1236),
     "c1_b16_s3": ("VIT_B16_T8", "3", 2, 3, 1237),
+    **{f"c1_b16_s{i}": ("VIT_B16_T8", "3", 2, i, 1234 + i) for i in range(4, 12)},     # tools/gen_golden.py --more-seeds
     "c3_clip0": ("VIT_B16_T16", "400", 1, 0, 3),
     "c5_clip0": ("VIT_L14_T32", "3", 1, 0, 5),
 }
+
+
+# Known deviation (measured in round 3 over twelve weight + input seeds at c1, tools/accuracy_sweep.py): the path's ABSOLUTE logit
+# error with fp16 MFMA operands is 2e-4 ... 9e-4 whatever the logits' size (it is exp(logit_scale) = 14.3 times the error of
+# a cosine of two unit vectors, 2e-5 ... 6e-5), and random-init models have small logits (largest |logit| 0.47 ... 1.6), so the
+# NORM-WISE bar max|d| <= 1e-3 max|ref| is met by ten of the twelve seeds (median 5.7e-4) and missed by these two (1.25e-3,
+# 1.51e-3).  The frozen mixed criterion holds on all of them (worst 0.93 of its bound).  The tests assert the norm-wise bar on
+# every seed and mark these two as expected failures (strict: an improvement of the numerics shows up as XPASS).
+NORMWISE_KNOWN_MISSES = ("c1_b16_s5", "c1_b16_s6")
 
 
 def golden_case(name):

@@ -77,7 +77,7 @@ def test_oracle_c1_vit_b16(golden_dir):
     assert np.array_equal(r["logits"].argmax(-1).numpy(), g["logits"].argmax(-1))
 
 
-@pytest.mark.parametrize("name", ["c1_b16_s1", "c1_b16_s2", "c1_b16_s3", "c3_clip0", "c5_clip0"])
+@pytest.mark.parametrize("name", ["c1_b16_s1", "c1_b16_s2", "c1_b16_s3", "c1_b16_s6", "c1_b16_s11", "c3_clip0", "c5_clip0"])
 def test_oracle_vs_round3_reference_fixtures(golden_dir, name):
     """The round-3 reference runs (tools/gen_golden.py --round3): three more weight + input seeds at c1, clip 0 of c3
     (16 frames, 400 classes) and of c5 (ViT-L/14, 32 frames).  Pins the oracle at the shapes the full-size GPU tests

@@ -318,6 +318,10 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     mod, txt_mod = import_reference()
     C3 = os.path.join(CLASSES, "updrs_3cls_classes.txt")
+    if "--more-seeds" in sys.argv:   # further weight + input seeds at c1 (statistics of the logits error; compact fixtures)
+        for sidx in range(4, 12):
+            run_case(mod, VIT_B16_T8, C3, 2, f"c1_b16_s{sidx}", False, wseed=sidx, xseed=1234 + sidx, compact=True)
+        sys.exit(0)
     if "--round3" in sys.argv:      # only the fixtures added in round 3: more seeds at c1, one clip at c3 and c5 shapes
         from gava_clip_amd.config import VIT_B16_T16, VIT_L14_T32
         for sidx in (1, 2, 3):      # other weights AND other clips than c1_b16.npz (wseed 0, xseed 1234)
