@@ -57,6 +57,7 @@ GOLDEN_LOGIT_CASES = {
     "c1_b16_s2": ("VIT_B16_T8", "3", 2, 2, 1236),
     "c1_b16_s3": ("VIT_B16_T8", "3", 2, 3, 1237),
     **{f"c1_b16_s{i}": ("VIT_B16_T8", "3", 2, i, 1234 + i) for i in range(4, 12)},     # tools/gen_golden.py --more-seeds
+    "c2_full": ("VIT_B16_T8", "3", 64, 0, 4242),                                        # tools/gen_golden.py --c2-full
     "c3_clip0": ("VIT_B16_T16", "400", 1, 0, 3),
     "c5_clip0": ("VIT_L14_T32", "3", 1, 0, 5),
 }

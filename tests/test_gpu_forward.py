@@ -362,6 +362,28 @@ def test_c2_full_size_batch_is_anchored_to_the_golden_and_deterministic(golden_d
     assert e_small < 5e-4
 
 
+def test_c2_full_batch_vs_the_reference(golden_dir):
+    """BASELINE config c2 end to end against the REFERENCE: all 64 clips of a full batch (tests/golden/c2_full.npz, a 64-clip
+    reference forward in the build container, tools/gen_golden.py --c2-full).  192 logits under the frozen mixed criterion,
+    every clip's video feature and the norm-wise bar on the whole logits matrix."""
+    g = np.load(os.path.join(golden_dir, "c2_full.npz"))
+    m, _ = build(VIT_B16_T8)
+    m.debug_taps = False
+    x = torch.from_numpy(synth.synth_clip(64, 8, 224, seed=int(g["xseed"])))
+    assert abs(float(x.double().sum()) - g["x_checksum"][0]) < 1e-3
+    with torch.no_grad():
+        lg = m(x.cuda())[0].cpu().numpy()
+    viol, e_rel = mixed_violation(lg, g["logits"]), rel_to_max(lg, g["logits"])
+    ev = rel_to_max(m.last["video_features"].cpu().numpy(), g["video_features"])
+    agree = int((lg.argmax(-1) == g["logits"].argmax(-1)).sum())
+    print(f"\n[c2 full vs reference] 192 logits (|ref| {np.abs(g['logits']).min():.3f}..{np.abs(g['logits']).max():.3f}): max|d| "
+          f"{np.abs(lg - g['logits']).max():.2e} rel-to-max {e_rel:.2e} mixed {viol:.3f}; video features {ev:.2e}; top-1 agrees on {agree}/64 clips")
+    assert viol <= 1.0
+    assert e_rel < 1e-3
+    assert ev < 1e-3
+    assert agree >= 63          # a clip whose two best logits differ by less than the path's error may flip
+
+
 def test_c3_full_size_batch_is_anchored_to_the_reference_and_deterministic(golden_dir):
     """BASELINE config c3 (32 clips, 16 frames, 400 classes, full depth): the logits of clip 0 meet the REFERENCE's for that
     clip alone (tests/golden/c3_clip0.npz, a reference run of 400 text passes; clips are independent), two runs are
