@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--no-alt", action="store_true", help="skip the short run in the other operand dtype")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the logits-vs-reference-golden check")
-    ap.add_argument("--accuracy-c5", action="store_true", help="include the ViT-L/14 fixture (c5_clip0) in the accuracy leg")
+    ap.add_argument("--accuracy-c5", action="store_true", help="include the full c3 batch and the ViT-L/14 fixtures (c5_clip0, c5_full) in the accuracy leg")
     return ap.parse_args()
 
 
@@ -230,7 +230,8 @@ def accuracy_vs_golden(prec, include_c5=False):
     from gava_clip_amd import VitaCLIP, synth
     from helpers import (GOLDEN_LOGIT_CASES, golden_case, model_kwargs, synth_torch_state, mixed_violation,
                          LOGITS_RTOL, LOGITS_ATOL)
-    names = [n for n in GOLDEN_LOGIT_CASES if include_c5 or not n.startswith("c5")]
+    # default: the twelve c1 seeds, the full c2 batch, clip 0 of c3; --accuracy-c5 adds the full c3 batch and the ViT-L/14 fixtures
+    names = [n for n in GOLDEN_LOGIT_CASES if include_c5 or not (n.startswith("c5") or n == "c3_full")]
     order = (prec, "bf16" if prec == "fp16" else "fp16")
     res = {"reference": "tests/golden/{%s}.npz (reference fp32 CPU forwards, tools/gen_golden.py)" % ",".join(names),
            "criteria": f"norm-wise max|d| <= 1e-3 max|ref|; element-wise |d| <= {LOGITS_RTOL} |ref| + {LOGITS_ATOL} (frozen, tests/helpers.py)"}

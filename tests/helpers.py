@@ -60,6 +60,8 @@ GOLDEN_LOGIT_CASES = {
     "c2_full": ("VIT_B16_T8", "3", 64, 0, 4242),                                        # tools/gen_golden.py --c2-full
     "c3_clip0": ("VIT_B16_T16", "400", 1, 0, 3),
     "c5_clip0": ("VIT_L14_T32", "3", 1, 0, 5),
+    "c3_full": ("VIT_B16_T16", "400", 32, 0, 4243),                                     # tools/gen_golden.py --c3-full
+    "c5_full": ("VIT_L14_T32", "3", 32, 0, 4244),                                       # tools/gen_golden.py --c5-full
 }
 
 

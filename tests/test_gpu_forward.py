@@ -440,6 +440,38 @@ def test_c5_full_size_vit_l14_t32_is_anchored_to_the_reference_and_deterministic
     assert viol <= 1.0
 
 
+@pytest.mark.parametrize("name,cfg_name,cls,n_cls", [("c3_full", "VIT_B16_T16", "400", 400), ("c5_full", "VIT_L14_T32", "3", 3)])
+def test_c3_c5_full_batch_vs_the_reference(golden_dir, name, cfg_name, cls, n_cls):
+    """BASELINE configs c3 (32 clips x 16 frames, 400 classes) and c5 per GPU (ViT-L/14, 32 clips x 32 frames) end to end against
+    the REFERENCE at their full batch (tests/golden/c3_full.npz / c5_full.npz: 32-clip reference forwards in the build
+    container, tools/gen_golden.py --c3-full / --c5-full): every logit under the frozen mixed criterion, the norm-wise bar on
+    the logits matrix, every clip's video feature."""
+    from helpers import CLASSES_400
+    from gava_clip_amd import config
+    path = os.path.join(golden_dir, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{name}.npz not generated")
+    g = np.load(path)
+    cfg = getattr(config, cfg_name)
+    m, _ = build(cfg, class_file=CLASSES_400 if cls == "400" else CLASSES_3, n_cls=n_cls)
+    m.debug_taps = False
+    x = torch.from_numpy(synth.synth_clip(32, cfg.num_frames, cfg.input_size, seed=int(g["xseed"])))
+    assert abs(float(x.double().sum()) - g["x_checksum"][0]) < 1e-2
+    with torch.no_grad():
+        lg = m(x.cuda())[0].cpu().numpy()
+    del x
+    viol, e_rel = mixed_violation(lg, g["logits"]), rel_to_max(lg, g["logits"])
+    ev = rel_to_max(m.last["video_features"].cpu().numpy(), g["video_features"])
+    et = rel_to_max(m.text_features.cpu().numpy(), g["text_features"])
+    agree = int((lg.argmax(-1) == g["logits"].argmax(-1)).sum())
+    print(f"\n[{name} vs reference] {lg.size} logits (max|ref| {np.abs(g['logits']).max():.3f}): max|d| {np.abs(lg - g['logits']).max():.2e} "
+          f"rel-to-max {e_rel:.2e} mixed {viol:.3f}; video features {ev:.2e} text features {et:.2e}; top-1 agrees on {agree}/32 clips")
+    assert viol <= 1.0
+    assert e_rel < 1e-3
+    assert ev < 1.5e-3 and et < 2e-5
+    assert agree >= 31
+
+
 def test_split_precision_last_block_is_an_exact_option(golden_dir):
     """model.split_last_block (GAVA_LAST_SPLIT=1): the last block's CLS rows through q_proj / out_proj / fc1 / fc2 in split
     precision.  Same results to the rounding of the 16-bit path (it removes one block's worth of operand rounding on B*T

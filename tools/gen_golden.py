@@ -318,6 +318,13 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     mod, txt_mod = import_reference()
     C3 = os.path.join(CLASSES, "updrs_3cls_classes.txt")
+    if "--c3-full" in sys.argv or "--c5-full" in sys.argv:   # BASELINE configs c3 / c5 (per GPU) at their full batch
+        from gava_clip_amd.config import VIT_B16_T16, VIT_L14_T32
+        if "--c3-full" in sys.argv:
+            run_case(mod, VIT_B16_T16, os.path.join(CLASSES, "k400_classes.txt"), 32, "c3_full", False, wseed=0, xseed=4243, compact=True)
+        if "--c5-full" in sys.argv:
+            run_case(mod, VIT_L14_T32, C3, 32, "c5_full", False, wseed=0, xseed=4244, compact=True)
+        sys.exit(0)
     if "--c2-full" in sys.argv:      # BASELINE config c2 at its full batch: 64 clips through the reference (logits + features only)
         run_case(mod, VIT_B16_T8, C3, 64, "c2_full", False, wseed=0, xseed=4242, compact=True)
         sys.exit(0)
