@@ -420,7 +420,11 @@ int launch_tile(GemmParams gp, int epi, hipStream_t s) {
 //     64-byte fp32 contiguous per lane, whole 128-byte lines per 4 lanes, no cross-lane shuffles.
 //     The W tile uses its own bank swizzle (bits 1,4,5 of the row) that is conflict-free for
 //     that read pattern.
-template <class P, int EPI, bool RES, bool SPLIT, bool FOLD = false>
+// ALIGN (round 3; the fp32-output instantiations): rounds of an XCD coincide with super-tiles.  An XCD's workgroups then
+// always work on ONE sm x sn block of tiles at a time (slot s = tile s of the block), whole blocks are dealt to the XCDs, and
+// every A panel is in flight once per block instead of drifting across rounds (per_xcd = 32 slots against 30-tile blocks
+// at N = 768: the plain walk fetches fc2's 620 MB A operand 1.5 times).  The launcher picks it only when it costs no extra round.
+template <class P, int EPI, bool RES, bool SPLIT, bool FOLD = false, bool ALIGN = false>
 __global__ __launch_bounds__(512, 2)
 void gemm256_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NW = 8;
@@ -467,14 +471,30 @@ void gemm256_kernel(const GemmParams p) {
   // ---- this workgroup's tiles: XCD-contiguous range, strided by the workgroups of the XCD
   const int nwg = p.n_tiles, nb = gridDim.x;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = nb >> 3;
-  const int q = nwg >> 3, r = nwg & 7;
+  // ALIGN: the units dealt to the XCDs are super-tile blocks (sm m-tiles x sn n-tiles, all chunks of an m-range in a row)
+  const int n_chunks = ALIGN ? p.tiles_n / p.sn : 1;
+  const int n_units = ALIGN ? ((p.tiles_m + p.sm - 1) / p.sm) * n_chunks : nwg;
+  const int q = n_units >> 3, r = n_units & 7;
   const int x_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   const int x_count = xcd < r ? q + 1 : q;
-  const int my_tiles = slot < x_count ? (x_count - slot + per_xcd - 1) / per_xcd : 0;
+  int my_tiles_ = slot < x_count ? (x_count - slot + per_xcd - 1) / per_xcd : 0;
+  if (ALIGN) {
+    // slot s is tile s of every block; the blocks of the last (short) m-range are the last n_chunks units overall
+    const int sm_last = p.tiles_m - ((p.tiles_m + p.sm - 1) / p.sm - 1) * p.sm;
+    my_tiles_ = slot >= p.sm * p.sn ? 0 : (slot >= sm_last * p.sn ? max(0, min(x_count, n_units - n_chunks - x_first)) : x_count);
+  }
+  const int my_tiles = my_tiles_;
   if (my_tiles == 0) return;
   const int nk = p.K / BK;
   const int G = my_tiles * nk;
   auto tile_coords = [&](int j, int& m0, int& n0) {
+    if (ALIGN) {
+      const int unit = x_first + j, mr = unit / n_chunks, ch = unit - mr * n_chunks;
+      const int first_m = mr * p.sm, sm = min(p.sm, p.tiles_m - first_m);
+      m0 = (first_m + slot % sm) * BM;
+      n0 = (ch * p.sn + slot / sm) * BN;
+      return;
+    }
     const int wg = x_first + slot + j * per_xcd;
     const int per_group = p.sm * p.tiles_n;
     const int g = wg / per_group, first_m = g * p.sm;
@@ -500,10 +520,16 @@ void gemm256_kernel(const GemmParams p) {
         const int chunk = (ln & 7) ^ ((row >> 1) & 7);
         int gm = m0 + row;
         gm = gm < p.M ? gm : p.M - 1;
+#ifdef GAVA_EXP_OPERAND_L2   // experiment builds (results WRONG): every tile reads the SAME A rows (1) and / or W rows (2), so that
+        if (p.pair_sleep & 1) gm = row;   // operand stays in L2 - what the k-loop would run at without fabric misses on it
+#endif
         src[i] = (unsigned)gm * (unsigned)p.lda + chunk * 8;
       } else {
         const int chunk = (ln & 7) ^ (NAT ? ((row >> 1) & 7) : (((row >> 1) & 1) | (((row >> 4) & 3) << 1)));
         src[i] = (unsigned)(n0 + row) * (unsigned)p.ldw + chunk * 8;
+#ifdef GAVA_EXP_OPERAND_L2
+        if (p.pair_sleep & 2) src[i] = (unsigned)row * (unsigned)p.ldw + chunk * 8;
+#endif
       }
     }
   };
@@ -988,6 +1014,20 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
   // (A W-stationary tile walk - an XCD stays on one chunk of weight panels and walks down the M-groups - was measured in
   // round 2, tools/r2_walk.sh: fabric fetch unchanged (FETCH_SIZE 421 -> 432 MB per fc1 launch), 3-6 % slower; removed.)
   dim3 grid(blocks), block(512);
+  // aligned walk (fp32-output kernels): blocks of sm x sn tiles with sm * sn <= workgroups per XCD, taken when sn divides the
+  // n-tiles, every XCD is full and the block count per XCD does not exceed the rounds of the plain walk; GAVA_TILE_ALIGN=0: off (A/B)
+  static const bool align_ok = !(getenv("GAVA_TILE_ALIGN") && getenv("GAVA_TILE_ALIGN")[0] == '0');
+  bool align = false;
+  // (the LayerNorm-folded consumers were measured with it too: fc1 0.5313 vs 0.5322 ms, no gain - their A operand is served by
+  // the Infinity Cache whatever the walk - so only the fp32-output kernels carry the instantiation)
+  if (align_ok && epi == GAVA_EPI_F32 && blocks == avail && gp.tiles_n % gp.sn == 0) {
+    const int per_xcd = blocks / 8, a_sm = per_xcd / gp.sn;
+    if (a_sm >= 1) {
+      const int units = ((gp.tiles_m + a_sm - 1) / a_sm) * (gp.tiles_n / gp.sn);
+      const int rounds_aligned = (units + 7) / 8, rounds_plain = ((gp.n_tiles + 7) / 8 + per_xcd - 1) / per_xcd;
+      if (rounds_aligned <= rounds_plain) { align = true; gp.sm = a_sm; }
+    }
+  }
 #define GAVA_LAUNCH(EPI, RES, SPLIT) hipLaunchKernelGGL((gemm256_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp)
   switch (epi) {
     case GAVA_EPI_H16:
@@ -1003,7 +1043,10 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
       } else if (gp.split_out) GAVA_LAUNCH(GAVA_EPI_H16_QGELU, false, true); else GAVA_LAUNCH(GAVA_EPI_H16_QGELU, false, false);
       break;
     case GAVA_EPI_F32:
-      if (gp.resid) GAVA_LAUNCH(GAVA_EPI_F32, true, false); else GAVA_LAUNCH(GAVA_EPI_F32, false, false);
+      if (align) {
+        if (gp.resid) hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, true, false, false, true>), grid, block, 0, s, gp);
+        else hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, false, false, false, true>), grid, block, 0, s, gp);
+      } else if (gp.resid) GAVA_LAUNCH(GAVA_EPI_F32, true, false); else GAVA_LAUNCH(GAVA_EPI_F32, false, false);
       break;
     case GAVA_EPI_F32_PATCH: GAVA_LAUNCH(GAVA_EPI_F32_PATCH, false, false); break;
     case GAVA_EPI_H16_QGELU_BWD:
@@ -1420,6 +1463,10 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.ablate = ablate;
 #else
   gp.ablate = 0;
+#endif
+#ifdef GAVA_EXP_OPERAND_L2
+  static const int opl2_ = getenv("GAVA_OPERAND_L2") ? atoi(getenv("GAVA_OPERAND_L2")) : 0;
+  gp.pair_sleep = opl2_;
 #endif
 #ifdef GAVA_EXP_STAGGER
   static const int pdelay_ = getenv("GAVA_PAIR_DELAY") ? atoi(getenv("GAVA_PAIR_DELAY")) : 0;
