@@ -424,6 +424,10 @@ int launch_tile(GemmParams gp, int epi, hipStream_t s) {
 // always work on ONE sm x sn block of tiles at a time (slot s = tile s of the block), whole blocks are dealt to the XCDs, and
 // every A panel is in flight once per block instead of drifting across rounds (per_xcd = 32 slots against 30-tile blocks
 // at N = 768: the plain walk fetches fc2's 620 MB A operand 1.5 times).  The launcher picks it only when it costs no extra round.
+// (Round 3 also tried a two-stage "touch" of the streaming A operand on top of it - waves 0-3 load one dword per 128-byte A line
+// of stage g+2 behind the LDS-DMA of stage g+1 and wait with vmcnt(1): fc2 0.586 vs 0.570 ms, forward 22.02 vs 21.75 ms, slower;
+// removed.  Its first version aborted the process: an asm load whose destination the compiler considers dead lands later in a
+// register that holds something else by then - an asynchronous destination needs a register live for as long as loads fly.)
 template <class P, int EPI, bool RES, bool SPLIT, bool FOLD = false, bool ALIGN = false>
 __global__ __launch_bounds__(512, 2)
 void gemm256_kernel(const GemmParams p) {
