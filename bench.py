@@ -197,9 +197,10 @@ def kernel_table(cfg, B, prec, fold=False):
     # inference forward launches it: with the fold, block 0's qkv and the last block run other kernels (forward.hip)
     Lyr = cfg.num_layers
     PN = "PrecF16" if prec == hip.PREC_F16 else "PrecBF16"
-    inst = {"qkv": f"gemm256_kernel<{PN}, 0, false, false, {'true' if fold else 'false'}>",
-            "fc1": f"gemm256_kernel<{PN}, 1, false, false, {'true' if fold else 'false'}>",
-            "out": f"gemm256_kernel<{PN}, 2, true, false, false>", "fc2": f"gemm256_kernel<{PN}, 2, true, false, false>"}
+    # template arguments: precision, epilogue, residual, split output, LayerNorm fold, aligned tile walk
+    inst = {"qkv": f"gemm256_kernel<{PN}, 0, false, false, {'true' if fold else 'false'}, false>",
+            "fc1": f"gemm256_kernel<{PN}, 1, false, false, {'true' if fold else 'false'}, false>",
+            "out": f"gemm256_kernel<{PN}, 2, true, false, false, true>", "fc2": f"gemm256_kernel<{PN}, 2, true, false, false, true>"}
     calls = {"qkv": Lyr - 2 if fold else Lyr - 1, "fc1": Lyr - 1, "out": Lyr - 1, "fc2": Lyr - 1}
     # per-layer order of the forward; the kernels the forward launches come first, at the positions they always had
     add("layernorm f32->h16 [R,D]", lambda: hip.layernorm(X, gam, bet, out16=Xn, prec=prec), 0, R * D * 6, "layernorm_kernel", 0, None)
