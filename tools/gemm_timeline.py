@@ -36,12 +36,14 @@ d = dbg.view(256, 2, 32).cpu().numpy().astype(np.float64)
 t0 = d[:, :, 0][d[:, :, 0] > 0].min()
 split = os.environ.get("TL_SPLIT") == "1"      # stagger builds: even and odd slots (blockIdx >> 3) of every XCD apart
 slot = (np.arange(256) >> 3) & 1
+if os.environ.get("TL_SPLIT_XCD") == "1":      # GAVA_STAGGER_MODE=2: XCDs 0-3 against XCDs 4-7
+    slot = ((np.arange(256) & 7) >= 4).astype(int)
 for grp, par in [(g_, p_) for g_ in (0, 1) for p_ in ((0, 1) if split else (None,))]:
     x = d[:, grp] if par is None else d[slot == par, grp]
     nt = x[:, 31].astype(int)
     print(f"== {which} wave group {grp}{'' if par is None else ' slot parity %d' % par}: tiles per workgroup {np.bincount(nt)[1:].tolist() if nt.max() else nt[:4]}")
     rows = []
-    for j in range(int(nt.max())):
+    for j in range(min(int(nt.max()), 10)):        # the kernel stamps the first ten tiles of a workgroup
         sel = nt > j
         ks, es, ee = x[sel, 3 * j] - t0, x[sel, 3 * j + 1] - t0, x[sel, 3 * j + 2] - t0
         nxt = np.where(nt[sel] > j + 1, x[sel, 3 * (j + 1)] - t0, x[sel, 30] - t0)     # next tile's k-loop start, or the kernel end
