@@ -2,10 +2,12 @@
 
 Follows video_dataset/dataset.py:117-139 (+ :163-186) step by step with the same torch calls, on the CPU:
 float()/255, (x-mean)/std, permute to (C,T,H,W), F.interpolate(bilinear, align_corners=False) of ALL frames to the
-short-side size, centre crop, temporal crop.  The arithmetic inside F.interpolate is third-party (torch); the
-reference holds no fixture for it and its own dataset module cannot be imported here (needs PyAV + torchvision),
-so this restatement is pinned only by being the same torch calls in the same order: "parity unpinned" by the
-reference's own files.  Imported by tests/ only; the product (gava_clip_amd/preprocess.py) never touches it.
+short-side size, centre crop, temporal crop.  The arithmetic inside F.interpolate is third-party (torch).  PINNED since
+round 3: tools/gen_golden.py --preprocess runs the reference's own VideoDataset.__getitem__ (its module imported with
+stand-ins for PyAV - a container that yields synthetic frames - and for torchvision, neither of which the evaluation
+branch uses after decoding) on nine synthetic videos; tests/test_preprocess.py checks that this restatement reproduces
+those outputs BIT FOR BIT (sha256 of the fp32 bytes, tests/golden/preprocess_ref.npz).  Imported by tests/ only; the
+product (gava_clip_amd/preprocess.py) never touches it.
 """
 import torch
 

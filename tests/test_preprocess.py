@@ -46,6 +46,23 @@ def test_short_video_repeats_last_frame():
     assert torch.equal(out[:, 2], out[:, 1]) and torch.equal(out[:, 3], out[:, 1])
 
 
+def test_oracle_reproduces_the_reference_dataset_bit_for_bit(golden_dir):
+    """tests/golden/preprocess_ref.npz holds what the REFERENCE's own VideoDataset.__getitem__ (evaluation branch,
+    video_dataset/dataset.py:78-139,163-200) returns for nine synthetic decoded videos (tools/gen_golden.py --preprocess: PyAV and
+    torchvision replaced by stand-ins, everything from `to_rgb().to_ndarray()` on is upstream's code), as the sha256 of the fp32
+    bytes and a strided sample.  The restatement must reproduce every byte: this pins the checker of the GPU input path
+     to the reference."""
+    import hashlib
+    import os
+    g = np.load(os.path.join(golden_dir, "preprocess_ref.npz"))
+    for i, (n, h, w, T, rate, size, sv, tv) in enumerate(g["cases"].tolist()):
+        seed = n * 1000 + h if sv == 1 and tv == 1 else n + h
+        v = _video(n, h, w, seed)
+        a = po.preprocess_clip(v, T, rate, size, MEAN, STD, num_spatial_views=sv, num_temporal_views=tv).contiguous().numpy()
+        assert np.array_equal(a.reshape(-1)[::max(1, a.size // 4096)][:4096], g[f"sample_{i}"]), i
+        assert hashlib.sha256(a.tobytes()).digest() == g[f"sha256_{i}"].tobytes(), i
+
+
 CASES = [  # n_frames, H, W, T, rate, size
     (20, 240, 320, 8, 2, 224),     # landscape, the usual UPDRS/K400 shape class
     (9, 320, 240, 8, 1, 224),      # portrait

@@ -302,6 +302,83 @@ def run_sigmoid_case(mod, cfg, class_file, B, name):
     print("wrote", path, out["logits"])
 
 
+def run_preprocess_cases():
+    """The evaluation branch of the REFERENCE's VideoDataset.__getitem__ (video_dataset/dataset.py:78-139,163-200) run on
+    synthetic decoded videos.  Its module needs PyAV and torchvision, which this container lacks: `av` is replaced by a
+    stand-in whose container yields frames carrying synthetic uint8 arrays (decoding is out of scope - SURVEY 8f row 3 starts
+    at the decoded frames), `torchvision` / the augmentation module by empty stand-ins (the evaluation branch never touches
+    them).  Everything from `to_rgb().to_ndarray()` on is the reference's own code.  Outputs are stored as sha256 of the fp32
+    bytes + a strided sample: the oracle (oracle/preprocess_oracle.py) must reproduce them bit for bit."""
+    import hashlib
+    import importlib
+    import tempfile
+
+    videos = {}
+
+    class _Frame:
+        def __init__(self, arr, pts):
+            self.arr, self.pts = arr, pts
+
+        def to_rgb(self):
+            return self
+
+        def to_ndarray(self):
+            return self.arr
+
+    class _Container:
+        def __init__(self, path):
+            self.frames = videos[os.path.basename(path)]
+
+        def decode(self, video=0):
+            for i in range(self.frames.shape[0] - 1, -1, -1):      # out of order on purpose: the reference sorts by pts
+                yield _Frame(self.frames[i], 40 * i)
+
+        def close(self):
+            pass
+
+    av = types.ModuleType("av")
+    av.open = lambda path: _Container(path)
+    sys.modules["av"] = av
+    tv = types.ModuleType("torchvision")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tv.transforms
+    pkg = types.ModuleType("video_dataset")
+    pkg.__path__ = [os.path.join(REF, "video_dataset")]
+    sys.modules["video_dataset"] = pkg
+    tr = types.ModuleType("video_dataset.transform")
+    tr.create_random_augment = tr.random_resized_crop = None
+    sys.modules["video_dataset.transform"] = tr
+    ds_mod = importlib.import_module("video_dataset.dataset")
+    assert ds_mod.__file__.startswith(REF)
+
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073])
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711])
+    # (n_frames, H, W, T, rate, size, spatial views, temporal views): tests/test_preprocess.py CASES + its multi-view cases
+    cases = [(20, 240, 320, 8, 2, 224, 1, 1), (9, 320, 240, 8, 1, 224, 1, 1), (5, 256, 256, 8, 1, 224, 1, 1),
+             (40, 360, 640, 16, 2, 224, 1, 1), (12, 224, 224, 8, 1, 224, 1, 1), (10, 181, 333, 4, 3, 96, 1, 1),
+             (30, 240, 320, 8, 2, 224, 1, 10), (30, 320, 240, 8, 2, 224, 3, 10), (12, 224, 400, 8, 2, 224, 3, 1)]
+    out = {"cases": np.array(cases, dtype=np.int64)}
+    with tempfile.TemporaryDirectory() as tmp:
+        for i, (n, h, w, T, rate, size, sv, tvw) in enumerate(cases):
+            seed = n * 1000 + h if sv == 1 and tvw == 1 else n + h          # the seeds tests/test_preprocess.py uses
+            rng = np.random.default_rng(seed)
+            videos[f"v{i}.mp4"] = rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8)
+            lst = os.path.join(tmp, f"list{i}.csv")
+            with open(lst, "w") as f:
+                f.write(f"v{i}.mp4,{i % 3}\n")
+            ds = ds_mod.VideoDataset(list_path=lst, data_root=tmp, num_spatial_views=sv, num_temporal_views=tvw, random_sample=False,
+                                     num_frames=T, sampling_rate=rate, spatial_size=size, mean=mean, std=std, is_train=False)
+            frames, label, name = ds[0]
+            assert tuple(frames.shape) == (3, T, size, size) and label == i % 3 and name == f"v{i}"
+            a = frames.contiguous().numpy()
+            out[f"sha256_{i}"] = np.frombuffer(hashlib.sha256(a.tobytes()).digest(), dtype=np.uint8)
+            out[f"sample_{i}"] = a.reshape(-1)[::max(1, a.size // 4096)][:4096].copy()
+            print("preprocess case", i, (n, h, w, T, rate, size, sv, tvw), "->", a.shape, hashlib.sha256(a.tobytes()).hexdigest()[:16])
+    path = os.path.join(REPO, "tests", "golden", "preprocess_ref.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)
+
+
 def dump_tokens(txt_mod):
     from gava_clip_amd.tokenizer import read_class_names, prompt_texts
     for fn in ("updrs_3cls_classes.txt", "k400_classes.txt"):
@@ -316,6 +393,9 @@ def dump_tokens(txt_mod):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if "--preprocess" in sys.argv:    # video_dataset/dataset.py only; the model modules are not imported
+        run_preprocess_cases()
+        sys.exit(0)
     mod, txt_mod = import_reference()
     C3 = os.path.join(CLASSES, "updrs_3cls_classes.txt")
     if "--c3-full" in sys.argv or "--c5-full" in sys.argv:   # BASELINE configs c3 / c5 (per GPU) at their full batch
