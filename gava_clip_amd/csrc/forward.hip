@@ -108,10 +108,13 @@ struct Fold {
   const float* partials = nullptr;                                                        // consumer, no row_stats launch
 };
 
-int gemm(const void* A, long lda, const void* W, long ldw, const float* bias, void* out, long ldo, int M, int N, int K,
-         int epi, int prec, gava_stream_t s, const float* resid = nullptr, long ldr = 0, int scale_cols = 0,
-         float scale = 1.f, int split_out = 0, void* aux_out = nullptr, const Fold* fold = nullptr, int cu_reserve = 0) {
+// w_lo (gava_gemm_args.w_lo = 1): W is packed [W_hi | W_lo]; `ldw` is still given as the row pitch of a plain weight (K columns)
+int gemm_x(int w_lo, const void* A, long lda, const void* W, long ldw, const float* bias, void* out, long ldo, int M, int N, int K,
+           int epi, int prec, gava_stream_t s, const float* resid = nullptr, long ldr = 0, int scale_cols = 0,
+           float scale = 1.f, int split_out = 0, void* aux_out = nullptr, const Fold* fold = nullptr, int cu_reserve = 0) {
   gava_gemm_args a{};
+  a.w_lo = w_lo ? 1 : 0;
+  if (w_lo) ldw *= 2;
   a.cu_reserve = cu_reserve;
   if (fold) {
     a.x16_out = fold->x16; a.ld_x16 = fold->ld_x16; a.rowsum_out = fold->rowsum; a.rowsum_reduced = fold->reduced;
@@ -121,6 +124,11 @@ int gemm(const void* A, long lda, const void* W, long ldw, const float* bias, vo
   a.resid = resid; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.prec = prec;
   a.scale_cols = scale_cols; a.scale = scale; a.split_out = split_out; a.aux_out = aux_out;
   return gava_gemm(&a, s);
+}
+int gemm(const void* A, long lda, const void* W, long ldw, const float* bias, void* out, long ldo, int M, int N, int K,
+         int epi, int prec, gava_stream_t s, const float* resid = nullptr, long ldr = 0, int scale_cols = 0,
+         float scale = 1.f, int split_out = 0, void* aux_out = nullptr, const Fold* fold = nullptr, int cu_reserve = 0) {
+  return gemm_x(0, A, lda, W, ldw, bias, out, ldo, M, N, K, epi, prec, s, resid, ldr, scale_cols, scale, split_out, aux_out, fold, cu_reserve);
 }
 
 struct VisionWs {
@@ -259,6 +267,9 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
   const int D = m->D, F = m->F, E = m->E, G = m->G, Tm = m->T_model, pr = m->prec;
   const int Kp = patch_k(m), SR = G + 2 * BT;
   const long fs = (long)(n + 1) * D;  // frame stride in X
+  // weight-lo pass (gava_vision_model.w_lo): every weight below except the *_split ones is [W_hi | W_lo], 2x the columns
+  const int wl = m->w_lo ? 1 : 0, WL = wl ? 2 : 1;
+  if (wl && saved_x) return GAVA_EINVAL;
   const char* h16 = nullptr; (void)h16;
 
   // ---- embedding (VitaCLIP_vision_encoder.py:105-113)
@@ -266,7 +277,7 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
     // im2col-free for fp32 clips, patch matrix + LDS-DMA GEMM for decoded uint8 videos: see patch_operand
     gava_gemm_args a{};
     TRY(patch_operand(m, x, w.HID, Kp, pr, stream, &a));
-    a.W = m->w_patch; a.ldw = Kp; a.bias = m->b_patch;
+    a.W = m->w_patch; a.ldw = WL * Kp; a.bias = m->b_patch; a.w_lo = wl;
     a.out = w.X; a.ldo = D; a.M = BT * n; a.N = D; a.K = Kp; a.epilogue = GAVA_EPI_F32_PATCH; a.prec = pr;
     a.pos = m->pos_embed; a.time = m->time_embed; a.n_patches = n; a.T = m->T_in;
     TRY(gava_gemm(&a, stream));
@@ -317,9 +328,9 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
         return GAVA_ELAUNCH;
     }
     TRY(ln(w.X, fs, nullptr, nullptr, nullptr, w.CLS16, D, nullptr, 0, BT, D, pr, ss));
-    TRY(gemm(w.CLS16, D, L.w_cls, D, L.b_cls, w.CP, D, BT, D, D, GAVA_EPI_F32, pr, ss));
+    TRY(gemm_x(wl, w.CLS16, D, L.w_cls, D, L.b_cls, w.CP, D, BT, D, D, GAVA_EPI_F32, pr, ss));
     TRY(ln(w.CP, D, nullptr, L.sln_g, L.sln_b, w.CPn, D, nullptr, 0, BT, D, pr, ss));
-    TRY(gemm(w.CPn, D, L.w_sqkv, D, L.b_sqkv, w.SQKV, 3 * D, BT, 3 * D, D, GAVA_EPI_H16, pr, ss, nullptr, 0, D, 0.125f));
+    TRY(gemm_x(wl, w.CPn, D, L.w_sqkv, D, L.b_sqkv, w.SQKV, 3 * D, BT, 3 * D, D, GAVA_EPI_H16, pr, ss, nullptr, 0, D, 0.125f));
     {
       gava_attention_args a{};
       const unsigned short* q = (const unsigned short*)w.SQKV;
@@ -327,9 +338,9 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       a.batch = BT / Tm; a.heads = m->H; a.n_q = Tm; a.n_kmain = Tm; a.prec = pr;
       TRY(gava_attention(&a, ss));
     }
-    TRY(gemm(w.SMIX, D, L.w_sout, D, L.b_sout, w.SUMM, D, BT, D, D, GAVA_EPI_F32, pr, ss, w.CP, D));
+    TRY(gemm_x(wl, w.SMIX, D, L.w_sout, D, L.b_sout, w.SUMM, D, BT, D, D, GAVA_EPI_F32, pr, ss, w.CP, D));
     TRY(gava::side_ln(L.global_prompts, L.local_prompts, w.CP, w.SUMM, L.ln1_g, L.ln1_b, w.SIDEn, G, Tm, BT, D, pr, (hipStream_t)ss));
-    TRY(gemm(w.SIDEn, D, wqkv + (long)D * D, D, L.b_qkv + D, w.SIDEKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, ss));
+    TRY(gemm_x(wl, w.SIDEn, D, wqkv + (long)D * WL * D, D, L.b_qkv + D, w.SIDEKV, 2 * D, SR, 2 * D, D, GAVA_EPI_H16, pr, ss));
     if (two && hipEventRecord(g_side.join[i], g_side.s) != hipSuccess) return GAVA_ELAUNCH;
     const int resv = two ? side_cus(folded_in) : 0;   // the persistent QKV GEMM leaves side_cus() CUs to the side kernels
     // main path.  LayerNorm folding (inference only, when the model carries the folded weights): norm2 of every block
@@ -358,9 +369,9 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       if (fold1) TRY(mark(GAVA_PROBE_QKV, i, 0));     // the folded form only: the instantiation bench.py's table names
       if (fold1) {
         Fold c = consume(L.qkv_fold_s, L.qkv_fold_t);
-        TRY(gemm(w.Xn, D, L.w_qkv_fold, D, nullptr, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, &c, resv));
+        TRY(gemm_x(wl, w.Xn, D, L.w_qkv_fold, D, nullptr, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, &c, resv));
       } else
-      TRY(gemm(w.Xn, D, L.w_qkv, D, L.b_qkv, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, nullptr, resv));
+      TRY(gemm_x(wl, w.Xn, D, L.w_qkv, D, L.b_qkv, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, nullptr, resv));
       if (fold1) TRY(mark(GAVA_PROBE_QKV, i, 1));
       if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
       {
@@ -377,28 +388,28 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       }
       TRY(mark(GAVA_PROBE_OUT, i, 0));
       if (fold2) {
-        TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
+        TRY(gemm_x(wl, w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
         TRY(mark(GAVA_PROBE_OUT, i, 1));
         if (!skip_stats && !fused) TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
         Fold c = consume(L.fc1_fold_s, L.fc1_fold_t);
         TRY(mark(GAVA_PROBE_FC1, i, 0));
-        TRY(gemm(w.Xn, D, L.w_fc1_fold, D, nullptr, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, &c));
+        TRY(gemm_x(wl, w.Xn, D, L.w_fc1_fold, D, nullptr, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, &c));
         TRY(mark(GAVA_PROBE_FC1, i, 1));
       } else {
-        TRY(gemm(w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D));
+        TRY(gemm_x(wl, w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D));
         TRY(mark(GAVA_PROBE_OUT, i, 1));
         TRY(ln(w.X, D, nullptr, L.ln2_g, L.ln2_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
         TRY(mark(GAVA_PROBE_FC1, i, 0));
-        TRY(gemm(w.Xn, D, L.w_fc1, D, L.b_fc1, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream));
+        TRY(gemm_x(wl, w.Xn, D, L.w_fc1, D, L.b_fc1, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream));
         TRY(mark(GAVA_PROBE_FC1, i, 1));
       }
       TRY(mark(GAVA_PROBE_FC2, i, 0));
       if (fold1_next) {
-        TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
+        TRY(gemm_x(wl, w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
         TRY(mark(GAVA_PROBE_FC2, i, 1));
         if (!skip_stats && !fused) TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
       } else {
-        TRY(gemm(w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D));
+        TRY(gemm_x(wl, w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D));
         TRY(mark(GAVA_PROBE_FC2, i, 1));
       }
       folded_in = fold1_next;
@@ -409,10 +420,10 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       // 1/197 of the row work.
       if (fold1) {   // norm1 folded into the K/V GEMM: Xn holds the 16-bit copy of the un-normalised stream
         Fold c = consume(L.qkv_fold_s + D, L.qkv_fold_t + D);
-        TRY(gemm(w.Xn, D, (const unsigned short*)L.w_qkv_fold + (long)D * D, D, nullptr, (unsigned short*)w.QKV + D, 3 * D, R, 2 * D, D,
+        TRY(gemm_x(wl, w.Xn, D, (const unsigned short*)L.w_qkv_fold + (long)D * WL * D, D, nullptr, (unsigned short*)w.QKV + D, 3 * D, R, 2 * D, D,
                  GAVA_EPI_H16, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, &c, resv));
       } else {
-        TRY(gemm(w.Xn, D, wqkv + (long)D * D, D, L.b_qkv + D, (unsigned short*)w.QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, nullptr, resv));
+        TRY(gemm_x(wl, w.Xn, D, wqkv + (long)D * WL * D, D, L.b_qkv + D, (unsigned short*)w.QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, nullptr, resv));
       }
       // split precision for these B*T rows when the model carries the split-packed weights (gava_vision_layer)
       const int sp = (!saved_x && L.w_q_split && L.w_out_split && L.w_fc1_split && L.w_fc2_split) ? 1 : 0;
@@ -422,9 +433,9 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
         TRY(gemm(w.XNC, 3 * D, L.w_q_split, 3 * D, L.b_qkv, w.QC, D, BT, D, 3 * D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
       } else if (fold1) {
         TRY(ln(w.X, fs, nullptr, L.ln1_g, L.ln1_b, w.XNC, D, nullptr, 0, BT, D, pr, stream));     // the B*T CLS rows only
-        TRY(gemm(w.XNC, D, L.w_qkv, D, L.b_qkv, w.QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+        TRY(gemm_x(wl, w.XNC, D, L.w_qkv, D, L.b_qkv, w.QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
       } else {
-        TRY(gemm(w.Xn, fs, L.w_qkv, D, L.b_qkv, w.QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
+        TRY(gemm_x(wl, w.Xn, fs, L.w_qkv, D, L.b_qkv, w.QC, D, BT, D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f));
       }
       if (two && hipStreamWaitEvent(s, g_side.join[i], 0) != hipSuccess) return GAVA_ELAUNCH;
       {
@@ -438,10 +449,10 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
         a.n_g = G; a.T = Tm; a.has_summary = 1; a.prec = pr;
         TRY(gava_attention(&a, stream));
       }
-      TRY(gemm(w.MIXC, S * D, sp ? L.w_out_split : L.w_out, S * D, L.b_out, w.X, fs, BT, D, S * D, GAVA_EPI_F32, pr, stream, w.X, fs));
+      TRY(gemm_x(sp ? 0 : wl, w.MIXC, S * D, sp ? L.w_out_split : L.w_out, S * D, L.b_out, w.X, fs, BT, D, S * D, GAVA_EPI_F32, pr, stream, w.X, fs));
       TRY(ln(w.X, fs, nullptr, L.ln2_g, L.ln2_b, w.XNC, S * D, nullptr, 0, BT, D, pr, stream, sp));
-      TRY(gemm(w.XNC, S * D, sp ? L.w_fc1_split : L.w_fc1, S * D, L.b_fc1, w.HIDC, S * F, BT, F, S * D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, sp));
-      TRY(gemm(w.HIDC, S * F, sp ? L.w_fc2_split : L.w_fc2, S * F, L.b_fc2, w.X, fs, BT, D, S * F, GAVA_EPI_F32, pr, stream, w.X, fs));
+      TRY(gemm_x(sp ? 0 : wl, w.XNC, S * D, sp ? L.w_fc1_split : L.w_fc1, S * D, L.b_fc1, w.HIDC, S * F, BT, F, S * D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, sp));
+      TRY(gemm_x(sp ? 0 : wl, w.HIDC, S * F, sp ? L.w_fc2_split : L.w_fc2, S * F, L.b_fc2, w.X, fs, BT, D, S * F, GAVA_EPI_F32, pr, stream, w.X, fs));
     }
     if (debug_cls) TRY(gava::copy_rows(w.X, fs, debug_cls + (long)i * BT * D, BT, D, s));
   }
@@ -465,6 +476,7 @@ extern "C" int gava_vision_forward_keep(const gava_vision_model* m, const float*
                                         const gava_vision_saved* sv, void* workspace, size_t workspace_bytes,
                                         gava_stream_t stream) {
   TRY(check_vision(m));
+  if (m->w_lo) return GAVA_EINVAL;     // the weight-lo pass is an inference mode (gava_hip.h)
   if ((!x && !m->clips) || !cls_x || !summary || !workspace || !sv || !sv->e0 || !sv->x || !sv->x1 || !sv->qkv || !sv->pre || !sv->sidekv)
     return GAVA_EINVAL;
   const VisionWs w = carve_vision(m, workspace, workspace_bytes);

@@ -74,6 +74,9 @@ struct GemmParams {
   int pair_sleep;   // experiment builds: s_sleep units after every epilogue chunk
   int ablate;   // timing probes, always 0 unless built with -DGAVA_ENABLE_ABLATE: 1 = no staging loads after the prologue,
                 // 2 = no LDS reads/MFMA, 4 = no epilogue
+  // weight-lo pass (gava_gemm_args.w_lo).  1: W rows are [W_hi | W_lo], the k-loop runs 2 K / BK stages and the A operand
+  // wraps after nka = K / BK of them
+  int w_lo, nka;
 };
 
 static __device__ __forceinline__ float aux_up(unsigned short u, int f16) {
@@ -132,11 +135,12 @@ void gemm_kernel(const GemmParams p) {
   }
   auto stage = [&](int kt) {
     char* base = smem + (kt % NST) * STAGE;
+    const int kta = kt >= p.nka ? kt - p.nka : kt;   // w_lo: the second half of the k-loop re-reads A
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int piece = wave + i * NW;
       if (direct && piece < BM / 8) continue;     // A tile comes from stage_patch_a()
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + (long)kt * BK), LDS_PTR(void, base + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + (long)(piece < BM / 8 ? kta : kt) * BK), LDS_PTR(void, base + piece * 1024), 16, 0, 0);
     }
   };
   // im2col-free patch operand: task = (row of the A tile, 16-byte chunk of 8 consecutive k).  k = (c,ky,kx);
@@ -145,7 +149,8 @@ void gemm_kernel(const GemmParams p) {
   // of the current k-tile, patch_write() converts and writes the LDS tile after them.
   constexpr int NTASK = BM * 8 / (NW * 64);
   float pe[NTASK][8];
-  auto patch_load = [&](int kt) {
+  auto patch_load = [&](int kt_) {
+    const int kt = kt_ >= p.nka ? kt_ - p.nka : kt_;
     const int P2 = p.patch * p.patch, Kreal = 3 * P2, g = p.fsize / p.patch;
 #pragma unroll
     for (int ti = 0; ti < NTASK; ++ti) {
@@ -212,7 +217,7 @@ void gemm_kernel(const GemmParams p) {
   const int a_row_off = (wr * 64 + fr) * 128;
   const int w_row_off = (wc * 64 + fr) * 128 + A_BYTES;
 
-  const int nk = p.K / BK;
+  const int nk = p.w_lo == 1 ? 2 * p.nka : p.nka;
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
     if (t < nk) { stage(t); if (direct) { patch_load(t); patch_write(t); } }
@@ -489,7 +494,7 @@ void gemm256_kernel(const GemmParams p) {
   }
   const int my_tiles = my_tiles_;
   if (my_tiles == 0) return;
-  const int nk = p.K / BK;
+  const int nk = p.w_lo == 1 ? 2 * p.nka : p.nka;
   const int G = my_tiles * nk;
   auto tile_coords = [&](int j, int& m0, int& n0) {
     if (ALIGN) {
@@ -540,6 +545,7 @@ void gemm256_kernel(const GemmParams p) {
     }
   };
   auto piece = [&](int slot, int kt, int i) {
+    if (i < PPW / 2 && kt >= p.nka) kt -= p.nka;    // w_lo: the second half of the k-loop re-reads A
     __builtin_amdgcn_global_load_lds(GLB_PTR((i < PPW / 2 ? p.A : p.W) + (size_t)(src[i] + (unsigned)(kt * BK))),
                                      LDS_PTR(void, smem + slot * STAGE + (wave + i * NW) * 1024), 16, 0, 0);
   };
@@ -1371,7 +1377,7 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   {
     const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
     const long tiles128 = (long)((gp.M + 127) / 128) * (gp.N / 256);
-    const bool can_pair = epi == GAVA_EPI_F32 && gp.N % 256 == 0 && gp.N <= 1024 && gp.K % 128 == 0 && fits && !gp.frames &&
+    const bool can_pair = !gp.w_lo && epi == GAVA_EPI_F32 && gp.N % 256 == 0 && gp.N <= 1024 && gp.K % 128 == 0 && fits && !gp.frames &&
                           !gp.clips && (gp.rowsum_reduced || !gp.x16);
     if (gp.kernel == GAVA_KERNEL_PAIR) return can_pair ? launch_pair<P>(gp, s) : GAVA_EINVAL;
     if (gp.kernel == GAVA_KERNEL_256) {
@@ -1419,7 +1425,9 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   if (!a || (!a->A && !patch_direct) || !a->W || !a->out) return GAVA_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return GAVA_EINVAL;
   if (a->N % 128 || a->K % BK) return GAVA_EINVAL;
-  if (a->ldw % 8 || a->ldw < a->K) return GAVA_EINVAL;
+  if (a->w_lo < 0 || a->w_lo > 2) return GAVA_EINVAL;
+  if (a->ldw % 8 || a->ldw < (a->w_lo == 1 ? 2 : 1) * (int64_t)a->K) return GAVA_EINVAL;
+  if (a->w_lo && (a->kernel == GAVA_KERNEL_PAIR || a->epilogue == GAVA_EPI_H16_QGELU_BWD)) return GAVA_EINVAL;
   if (!patch_direct && (a->lda % 8 || a->lda < a->K)) return GAVA_EINVAL;
   if (patch_direct && (a->patch <= 0 || a->frame_size % a->patch || 3 * a->patch * a->patch > a->K ||
                        (a->frame_size / a->patch) * (a->frame_size / a->patch) != a->n_patches ||
@@ -1464,6 +1472,7 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.cu_reserve = a->cu_reserve;
   gp.kernel = a->kernel;
   gp.pair_delay = 0; gp.pair_sleep = 0;
+  gp.w_lo = a->w_lo; gp.nka = a->K / BK;
 #ifdef GAVA_ENABLE_ABLATE   // timing-probe builds only (tools/ab_build.sh NAME -DGAVA_ENABLE_ABLATE): results are WRONG by design
   static const int ablate = getenv("GAVA_GEMM_ABLATE") ? atoi(getenv("GAVA_GEMM_ABLATE")) : 0;
   gp.ablate = ablate;

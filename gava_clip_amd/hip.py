@@ -38,7 +38,9 @@ class GemmArgs(C.Structure):
                 ("x16_out", _vp), ("ld_x16", C.c_int64), ("rowsum_out", _fp),
                 ("fold_stats", _fp), ("fold_s", _fp), ("fold_t", _fp), ("cu_reserve", C.c_int),
                 ("rowsum_reduced", C.c_int), ("fold_partials", _fp),
-                ("clips", _vp), ("clip_lut", _fp), ("kernel", C.c_int)]
+                ("clips", _vp), ("clip_lut", _fp), ("kernel", C.c_int),
+                ("w_lo", C.c_int), ("A8", _vp), ("lda8", C.c_int64), ("W8", _vp), ("ldw8", C.c_int64), ("w8_exp", C.c_int),
+                ("out8", _vp), ("ldo8", C.c_int64), ("x8_out", _vp), ("ld_x8", C.c_int64)]
 
 
 class LayerNormArgs(C.Structure):
@@ -80,7 +82,12 @@ class VisionModel(C.Structure):
                 ("w_patch", _vp), ("b_patch", _fp), ("cls_token", _fp), ("pos_embed", _fp), ("time_embed", _fp),
                 ("lnpre_g", _fp), ("lnpre_b", _fp), ("lnpost_g", _fp), ("lnpost_b", _fp),
                 ("w_proj", _vp), ("layer", C.POINTER(VisionLayer)),
-                ("clips", _vp), ("clip_lut", _fp)]
+                ("clips", _vp), ("clip_lut", _fp), ("w_lo", C.c_int), ("layer8", _vp)]
+
+
+class VisionLayer8(C.Structure):
+    _fields_ = [(n, _vp) for n in ("w_qkv8", "w_out8", "w_fc18", "w_fc28", "w_qkv_fold8", "w_fc1_fold8")] + \
+               [(n, C.c_int) for n in ("qkv_exp", "out_exp", "fc1_exp", "fc2_exp", "qkv_fold_exp", "fc1_fold_exp")]
 
 
 class TextLayer(C.Structure):
@@ -245,9 +252,14 @@ def h16_dtype(prec):
 def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0,
          pos=None, time=None, n_patches=0, T=0, M=None, split_out=False, frames=None, frame_size=0, patch=0, aux=None,
          aux_prec=None, aux_out=None, x16_out=None, rowsum_out=None, fold_stats=None, fold_s=None, fold_t=None,
-         cu_reserve=0, rowsum_reduced=False, fold_partials=None, clips=None, clip_lut=None, kernel=0):
+         cu_reserve=0, rowsum_reduced=False, fold_partials=None, clips=None, clip_lut=None, kernel=0, w_lo=0, K=None,
+         A8=None, W8=None, w8_exp=0, out8=None, x8_out=None):
     a = GemmArgs()
     a.kernel = kernel
+    a.w_lo, a.w8_exp = w_lo, w8_exp
+    a.A8, a.lda8, a.W8, a.ldw8 = ptr(A8), (A8.stride(0) if A8 is not None else 0), ptr(W8), (W8.stride(0) if W8 is not None else 0)
+    a.out8, a.ldo8 = ptr(out8), (out8.stride(0) if out8 is not None else 0)
+    a.x8_out, a.ld_x8 = ptr(x8_out), (x8_out.stride(0) if x8_out is not None else 0)
     a.clips, a.clip_lut = ptr(clips), ptr(clip_lut)
     a.cu_reserve = cu_reserve
     a.rowsum_reduced, a.fold_partials = int(rowsum_reduced), ptr(fold_partials)
@@ -259,7 +271,7 @@ def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0
     a.frames, a.frame_size, a.patch = ptr(frames), frame_size, patch
     a.bias, a.out, a.ldo = ptr(bias), ptr(out), out.stride(0)
     a.resid, a.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
-    a.M, a.N, a.K = (A.shape[0] if M is None else M), W.shape[0], W.shape[1]
+    a.M, a.N, a.K = (A.shape[0] if M is None else M), W.shape[0], (W.shape[1] // (2 if w_lo == 1 else 1) if K is None else K)
     a.epilogue, a.prec, a.scale_cols, a.scale = epilogue, prec, scale_cols, scale
     a.pos, a.time, a.n_patches, a.T = ptr(pos), ptr(time), n_patches, T
     a.split_out = int(split_out)

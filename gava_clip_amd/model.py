@@ -338,7 +338,7 @@ class _HipHost:
 
     def _hip_init(self, shape, operand_dtype=None):
         operand_dtype = operand_dtype or os.environ.get("GAVA_PREC", "fp16")
-        self.prec = hip.PREC_NAMES[operand_dtype]
+        self.prec, self.w_lo = self._parse_operand_dtype(operand_dtype)
         # text tower GEMMs in split precision (hi+lo operands, 3 MFMA passes): the text side is <1 % of
         # the work at the headline configs but dominates the logits error at plain 16-bit operands
         self.text_split_precision = os.environ.get("GAVA_TEXT_SPLIT", "1") != "0"
@@ -372,8 +372,21 @@ class _HipHost:
         self.last = {}
 
     # ---- weight packing -----------------------------------------------------------------------
+    @staticmethod
+    def _parse_operand_dtype(name):
+        """"fp16" | "bf16", optionally "+wlo" / "+wlo8": the weight-lo pass of the vision tower in inference (include/gava_hip.h,
+        gava_gemm_args.w_lo; DESIGN.md "Numerics") - the 16-bit rounding of the frozen weights is what misses north_star's 1e-3
+        on some models, so every vision GEMM also multiplies by W - h16(W): "+wlo" as a second 16-bit k-loop over the
+        re-read activations, "+wlo8" at 8 bits (block-scaled MFMA, twice the rate) for the four full-width GEMMs of a block."""
+        base, _, mode = name.partition("+")
+        if mode not in ("", "wlo", "wlo8") or base not in hip.PREC_NAMES:
+            raise ValueError(f"operand_dtype must be fp16 | bf16 [+wlo | +wlo8], got {name!r}")
+        if mode == "wlo8" and hip.PREC_NAMES[base] != hip.PREC_F16:
+            raise ValueError("the 8-bit weight-lo pass takes its bf8 activations from fp16 operands: use fp16+wlo8")
+        return hip.PREC_NAMES[base], {"": 0, "wlo": 1, "wlo8": 2}[mode]
+
     def set_operand_dtype(self, name: str):
-        self.prec = hip.PREC_NAMES[name]
+        self.prec, self.w_lo = self._parse_operand_dtype(name)
         self._packed = None
 
     _PASS_THROUGH = ("prompt_learner.", "logit_scale", "global_prompts", "local_prompts", "token_embedding",
@@ -395,7 +408,7 @@ class _HipHost:
                           blk.attn.k_proj.bias, blk.attn.v_proj.bias, blk.mlp.fc1.bias):
                     ver += q._version
         ps = next(self.parameters())
-        return (self.prec, self.text_split_precision, self.trim_text_rows, self.fold_layernorm, self.split_last_block,
+        return (self.prec, self.w_lo, self.text_split_precision, self.trim_text_rows, self.fold_layernorm, self.split_last_block,
                 ps.device, addr, ver)
 
     def _summary_weight_versions(self):
@@ -419,6 +432,10 @@ class _HipHost:
                 packed["w_sqkv"][i].copy_(self._h16(torch.cat([s_.q_proj.weight, s_.k_proj.weight, s_.v_proj.weight], 0)))
                 packed["w_sout"][i].copy_(self._h16(s_.out_proj.weight))
                 packed["b_sqkv"][i].copy_(torch.cat([s_.q_proj.bias, s_.k_proj.bias, s_.v_proj.bias], 0).detach().float())
+                if "w_sqkv_wlo" in packed:
+                    packed["w_sqkv_wlo"][i].copy_(self._hl16(torch.cat([s_.q_proj.weight, s_.k_proj.weight, s_.v_proj.weight], 0)))
+                    packed["w_sout_wlo"][i].copy_(self._hl16(s_.out_proj.weight))
+                    packed["b_sqkv_wlo"][i].copy_(torch.cat([s_.q_proj.bias, s_.k_proj.bias, s_.v_proj.bias], 0).detach().float())
         packed["summary_ver"] = cur
 
     def _pack_vision_backward(self):
@@ -463,13 +480,27 @@ class _HipHost:
         self._packed, self._packed_key = packed, key
         return packed
 
+    def _hl16(self, t):
+        """[N][K] fp32 -> [N][2K] h16 = [W_hi | W_lo], W_lo = h16(W - W_hi): the weight side of gava_gemm_args.w_lo = 1."""
+        t = t.detach().float().contiguous()
+        hi = hip.convert_h16(t, self.prec)
+        return torch.cat([hi, hip.convert_h16(t - hi.float(), self.prec)], dim=1).contiguous()
+
     def _pack_vision(self, packed, K, w_sqkv_t, w_sout_t, b_sqkv_t):
+        self._pack_vision_set(packed, K, w_sqkv_t, w_sout_t, b_sqkv_t, 0)
+        if self.w_lo:
+            # inference with the weight-lo pass: a second set of structs whose 16-bit weights are [W_hi | W_lo]; the training
+            # drivers keep using the plain set (fp32 pass-through tensors are shared by address: K() dedups nothing, they are views)
+            self._pack_vision_set(packed, K, [], [], [], self.w_lo)
+
+    def _pack_vision_set(self, packed, K, w_sqkv_t, w_sout_t, b_sqkv_t, w_lo):
         sh, v = self._shape, self.visual
+        h16 = self._hl16 if w_lo else self._h16
         Kp = (3 * sh["P"] ** 2 + 63) // 64 * 64
         wpatch = v.patch_embed.proj.weight.detach().float().reshape(sh["D"], -1)
         if Kp != wpatch.shape[1]:
             wpatch = F.pad(wpatch, (0, Kp - wpatch.shape[1]))
-        vis = dict(w_patch=K(self._h16(wpatch)), b_patch=K(self._f32(v.patch_embed.proj.bias)),
+        vis = dict(w_patch=K(h16(wpatch)), b_patch=K(self._f32(v.patch_embed.proj.bias)),
                    cls_token=K(self._f32(v.cls_token)), pos_embed=K(self._f32(v.pos_embed)),
                    lnpre_g=K(self._f32(v.ln_pre.weight)), lnpre_b=K(self._f32(v.ln_pre.bias)),
                    lnpost_g=K(self._f32(v.ln_post.weight)), lnpost_b=K(self._f32(v.ln_post.bias)),
@@ -478,11 +509,11 @@ class _HipHost:
         for i, blk in enumerate(v.blocks):
             a, s = blk.attn, blk.summary_attn_layer
             L = layers[i]
-            L.w_qkv = K(self._h16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)))
+            L.w_qkv = K(h16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)))
             L.b_qkv = K(self._f32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)))
-            L.w_out, L.b_out = K(self._h16(a.out_proj.weight)), K(self._f32(a.out_proj.bias))
-            L.w_fc1, L.b_fc1 = K(self._h16(blk.mlp.fc1.weight)), K(self._f32(blk.mlp.fc1.bias))
-            L.w_fc2, L.b_fc2 = K(self._h16(blk.mlp.fc2.weight)), K(self._f32(blk.mlp.fc2.bias))
+            L.w_out, L.b_out = K(h16(a.out_proj.weight)), K(self._f32(a.out_proj.bias))
+            L.w_fc1, L.b_fc1 = K(h16(blk.mlp.fc1.weight)), K(self._f32(blk.mlp.fc1.bias))
+            L.w_fc2, L.b_fc2 = K(h16(blk.mlp.fc2.weight)), K(self._f32(blk.mlp.fc2.bias))
             L.ln1_g, L.ln1_b = K(self._f32(blk.norm1.weight)), K(self._f32(blk.norm1.bias))
             L.ln2_g, L.ln2_b = K(self._f32(blk.norm2.weight)), K(self._f32(blk.norm2.bias))
             if self.fold_layernorm:
@@ -493,8 +524,9 @@ class _HipHost:
                 for tag, w0, b0, nrm in (("qkv", wq, bq, blk.norm1), ("fc1", blk.mlp.fc1.weight.detach().float(),
                                                                      blk.mlp.fc1.bias.detach().float(), blk.norm2)):
                     gam, bet = nrm.weight.detach().float(), nrm.bias.detach().float()
-                    wf = self._h16(w0 * gam)
+                    wf = h16(w0 * gam)
                     setattr(L, f"w_{tag}_fold", K(wf))
+                    # ([W_hi | W_lo]: the row sum over both halves = the sum of the weight the kernel multiplies by)
                     setattr(L, f"{tag}_fold_s", K(wf.float().sum(1).contiguous()))
                     setattr(L, f"{tag}_fold_t", K((w0.double() @ bet.double() + b0.double()).float().contiguous()))
             if self.split_last_block and i == len(v.blocks) - 1:
@@ -502,17 +534,20 @@ class _HipHost:
                 L.w_out_split = K(hip.split_pack_weight(a.out_proj.weight, self.prec))
                 L.w_fc1_split = K(hip.split_pack_weight(blk.mlp.fc1.weight, self.prec))
                 L.w_fc2_split = K(hip.split_pack_weight(blk.mlp.fc2.weight, self.prec))
-            L.w_cls, L.b_cls = K(self._h16(blk.cls_proj.weight)), K(self._f32(blk.cls_proj.bias))
+            L.w_cls, L.b_cls = K(h16(blk.cls_proj.weight)), K(self._f32(blk.cls_proj.bias))
             L.sln_g, L.sln_b = K(self._f32(blk.summary_ln.weight)), K(self._f32(blk.summary_ln.bias))
-            w_sqkv_t.append(self._h16(torch.cat([s.q_proj.weight, s.k_proj.weight, s.v_proj.weight], 0)))
-            w_sout_t.append(self._h16(s.out_proj.weight))
+            w_sqkv_t.append(h16(torch.cat([s.q_proj.weight, s.k_proj.weight, s.v_proj.weight], 0)))
+            w_sout_t.append(h16(s.out_proj.weight))
             L.w_sqkv, L.w_sout = K(w_sqkv_t[-1]), K(w_sout_t[-1])
             b_sqkv_t.append(self._f32(torch.cat([s.q_proj.bias, s.k_proj.bias, s.v_proj.bias], 0)))
             L.b_sqkv = K(b_sqkv_t[-1])
             L.b_sout = K(self._f32(s.out_proj.bias))
             L.local_prompts = K(self._f32(blk.local_prompts[0]))
             L.global_prompts = K(self._f32(v.global_prompts[i]))
-        packed.update(vis=vis, vis_layers=layers, w_sqkv=w_sqkv_t, w_sout=w_sout_t, b_sqkv=b_sqkv_t)
+        if w_lo:
+            packed.update(vis_wlo=vis, vis_layers_wlo=layers, w_sqkv_wlo=w_sqkv_t, w_sout_wlo=w_sout_t, b_sqkv_wlo=b_sqkv_t)
+        else:
+            packed.update(vis=vis, vis_layers=layers, w_sqkv=w_sqkv_t, w_sout=w_sout_t, b_sqkv=b_sqkv_t)
 
     def _pack_text(self, packed, K):
         sh = self._shape
@@ -588,10 +623,12 @@ class _HipHost:
         for k in ("size", "P", "D", "H", "layers", "F", "E", "G"):
             setattr(m, k, sh[k])
         m.prec = self.prec
-        for k, val in pk["vis"].items():
+        wl = self.w_lo if (saved is None and kept is None) else 0      # the weight-lo pass is an inference mode
+        for k, val in pk["vis_wlo" if wl else "vis"].items():
             setattr(m, k, val)
         m.time_embed = C.c_void_p(te.data_ptr())
-        m.layer = C.cast(pk["vis_layers"], C.POINTER(hip.VisionLayer))
+        m.layer = C.cast(pk["vis_layers_wlo" if wl else "vis_layers"], C.POINTER(hip.VisionLayer))
+        m.w_lo = 1 if wl else 0
         if clips is not None:
             m.clips, m.clip_lut = hip.ptr(desc), hip.ptr(lut)
         nbytes = lib.gava_vision_workspace_bytes(C.byref(m))

@@ -134,6 +134,22 @@ typedef struct {
    * residual-stream GEMMs out_proj / fc2 and their folding-producer form; N % 256 == 0, N <= 1024, K % 128 == 0).  A named
    * kernel that does not take the shape is rejected (GAVA_EINVAL), never replaced. */
   int kernel;
+  /* Weight-lo pass (DESIGN.md "Numerics", round 4).  With 16-bit operands the rounding of the frozen WEIGHTS, not of the
+   * activations, sets the logits error (tools/error_budget.py), so the product can be completed by A . W_lo^T with
+   * W_lo = W - h16(W) while A stays a single 16-bit operand:
+   *   w_lo = 1: W rows are [W_hi (K) | W_lo (K)] h16, ldw >= 2K; the k-loop runs 2K deep and re-reads A for the second half
+   *             (nothing is stored twice).  K stays the number of columns of A.  Every kernel but GAVA_KERNEL_PAIR.
+   *   w_lo = 2: the lo product at 8 bits on the block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4: twice the 16-bit
+   *             rate): after the K-deep 16-bit loop, K more columns with A8 = bf8 (e5m2) copy of A, bytes [M][lda8], and
+   *             W8 = e4m3 rows [N][ldw8] holding 2^w8_exp * W_lo (the MFMA's E8M0 scale operand takes the 2^-w8_exp back, so
+   *             both products share the accumulators).  W stays [N][K] = W_hi.  K % 128 == 0, lda8 / ldw8 % 16 == 0;
+   *             the persistent 256 x 256 kernel only (rejected elsewhere, never replaced).
+   * Producers of a w_lo = 2 operand: out8 (EPI_H16 / EPI_H16_QGELU) = bf8 copy of the 16-bit output rows, bytes [M][ldo8];
+   * x8_out (EPI_F32 with x16_out) = bf8 copy of x16_out, bytes [M][ld_x8].  bf8 = the fp16 value rounded to 2 mantissa
+   * bits (fp16 operands only). */
+  int w_lo;
+  const void* A8; int64_t lda8; const void* W8; int64_t ldw8; int w8_exp;
+  void* out8; int64_t ldo8; void* x8_out; int64_t ld_x8;
 } gava_gemm_args;
 #define GAVA_KERNEL_AUTO 0
 #define GAVA_KERNEL_256 3
@@ -238,7 +254,22 @@ typedef struct {
   const gava_vision_layer* layer;              /* host array [layers]                         */
   /* optional uint8 input (gava_gemm_args.clips): when clips != NULL the drivers' `x` argument is ignored (may be NULL) */
   const gava_clip_desc* clips; const float* clip_lut;   /* fp32 [3][256], see gava_gemm_args */
+  /* Weight-lo pass (gava_gemm_args.w_lo), inference drivers only (gava_vision_forward; the training drivers reject it).
+   * w_lo = 1: w_patch and every 16-bit weight of gava_vision_layer except the *_split ones are packed [W_hi | W_lo] with
+   * twice the columns ([3D][2D], [F][2D], [D][2F], ...; the folded copies too, their fold_s = row sums of hi + lo).
+   * w_lo = 2: as 1, and the four full-width GEMMs of a block (qkv, out_proj, fc1, fc2 over all B*T*(n+1) rows) run their
+   * lo product at 8 bits from the layer's *8 weights (gava_vision_layer8), activations leaving their producers with a bf8 copy. */
+  int w_lo;
+  const struct gava_vision_layer8* layer8;     /* host array [layers], w_lo = 2 only */
 } gava_vision_model;
+
+/* e4m3 rows of 2^exp * W_lo for the 8-bit lo product (gava_gemm_args.W8 / w8_exp): [3D][D], [D][D], [F][D], [D][F] bytes;
+ * qkv / fc1: of the LayerNorm-folded weight when the layer carries one (blocks whose norm is folded), else of the plain one. */
+typedef struct gava_vision_layer8 {
+  const void* w_qkv8; const void* w_out8; const void* w_fc18; const void* w_fc28;
+  const void* w_qkv_fold8; const void* w_fc1_fold8;
+  int qkv_exp, out_exp, fc1_exp, fc2_exp, qkv_fold_exp, fc1_fold_exp;
+} gava_vision_layer8;
 
 /* CLIPVisionEncoder.forward (VitaCLIP_vision_encoder.py:102-132).
  * x: fp32 (B,3,T_in,size,size) contiguous.  cls_x: fp32 [B][E] (un-normalised, :126-128),

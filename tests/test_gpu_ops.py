@@ -552,3 +552,94 @@ def test_attention_f32_core(prec, batch, heads, L, causal, split):
     assert float((got - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
     with pytest.raises(hip.GavaError):
         hip.attention_f32(qkv[:, :Wd], qkv[:, Wd:2 * Wd], qkv[:, 2 * Wd:], out, batch=1, heads=heads, L=129, prec=prec)
+
+
+def _hi_lo(W, dt):
+    hi = W.to(dt)
+    return hi, (W - hi.float()).to(dt)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (1000, 384, 768), (4100, 768, 768), (45000, 768, 3072), (30000, 2304, 768)])
+def test_gemm_weight_lo_pass(prec, M, N, K):
+    """gava_gemm_args.w_lo = 1: W packed [W_hi | W_lo], the k-loop runs 2K deep and re-reads A.  The product must equal
+    A16 . (W_hi + W_lo)^T, i.e. the 16-bit ACTIVATIONS times the (almost) exact weights - and be far closer to A16 . W^T
+    than the plain 16-bit GEMM, whose error is the rounding of W (VERDICT r3 / tools/error_budget.py).  Shapes cover the
+    128^2 tile kernel, the persistent 256^2 kernel (fp32 output with residual: fc2 / out_proj; 16-bit output: qkv)."""
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    A = rnd((M, K), 1.0, 1).to(d).to(dt)
+    Wf = rnd((N, K), K ** -0.5, 2).to(d)
+    hi, lo = _hi_lo(Wf, dt)
+    Wp = torch.cat([hi, lo], 1).contiguous()
+    bias = rnd((N,), 0.5, 3).to(d)
+    exact = A.double() @ Wf.double().t() + bias.double()
+    X0 = rnd((M, N), 1.0, 4).to(d)
+    X = X0.clone()
+    hip.gemm(A, Wp, bias, X, epilogue=hip.EPI_F32, prec=prec, resid=X, w_lo=1)
+    want = (X0.double() + A.double() @ (hi.double() + lo.double()).t() + bias.double())
+    assert torch.allclose(X.double(), want, rtol=2e-5, atol=2e-5)
+    Y = X0.clone()
+    hip.gemm(A, hi.contiguous(), bias, Y, epilogue=hip.EPI_F32, prec=prec, resid=Y)
+    e_lo = float((X.double() - X0.double() - exact).abs().max()); e_plain = float((Y.double() - X0.double() - exact).abs().max())
+    print(f"\n[w_lo {M}x{N}x{K} prec {prec}] max error vs A16.W^T: with lo {e_lo:.2e}, plain {e_plain:.2e}")
+    assert e_lo < 0.12 * e_plain
+    # 16-bit output epilogues
+    out = torch.zeros(M, N, dtype=dt, device=d)
+    hip.gemm(A, Wp, bias, out, epilogue=hip.EPI_H16_QGELU, prec=prec, w_lo=1)
+    r = (want - X0.double()).float()
+    r = r * torch.sigmoid(1.702 * r)
+    tol = 4 * EPS16[prec]
+    assert torch.allclose(out.float(), r, rtol=tol, atol=2 * tol)
+    # rejected: the pair kernel has no lo pass; ldw must cover both halves
+    with pytest.raises(hip.GavaError):
+        hip.gemm(A, Wp, bias, X, epilogue=hip.EPI_F32, prec=prec, resid=X, w_lo=1, kernel=hip.KERNEL_PAIR)
+    with pytest.raises(hip.GavaError):
+        hip.gemm(A, hi.contiguous(), bias, X, epilogue=hip.EPI_F32, prec=prec, resid=X, w_lo=1, K=K)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_gemm_weight_lo_with_folded_layernorm_and_patch_loader(prec):
+    """w_lo = 1 together with the consumers' LayerNorm fold (fold_s = row sums of hi + lo; stats and partials modes) and with
+    the im2col-free patch loader (the A tile is rebuilt for the second half of the k-loop)."""
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    M, D = 20000, 768
+    X = (rnd((M, D), 1.0, 4) + 0.3).to(d)
+    x16 = X.to(dt)
+    Mp = (M + 255) // 256 * 256
+    part = torch.zeros(Mp + 32, 4, 2, dtype=torch.float32, device=d)
+    xf = x16.float()          # the statistics are those of the fp32 stream
+    for sl in range(D // 256):
+        seg = X[:, sl * 256:(sl + 1) * 256]
+        part[:M, sl, 0], part[:M, sl, 1] = seg.sum(1), (seg * seg).sum(1)
+    mean, var = X.mean(1), X.var(1, unbiased=False)
+    stats = torch.zeros(Mp, 2, device=d); stats[:M, 0], stats[:M, 1] = mean, (var + 1e-5).rsqrt()
+    gamma, beta = (1 + rnd((D,), 0.2, 5)).to(d), rnd((D,), 0.2, 6).to(d)
+    N = 2304
+    W = rnd((N, D), D ** -0.5, 7).to(d)
+    b = rnd((N,), 0.3, 8).to(d)
+    hi, lo = _hi_lo(W * gamma, dt)
+    Wp = torch.cat([hi, lo], 1).contiguous()
+    fs, ft = (hi.float() + lo.float()).sum(1).contiguous(), (W @ beta + b).contiguous()
+    want = stats[:M, 1:2] * (xf @ (hi.float() + lo.float()).t() - stats[:M, 0:1] * fs) + ft
+    for kw in (dict(fold_stats=stats), dict(fold_partials=part)):
+        out = torch.zeros(M, N, dtype=dt, device=d)
+        hip.gemm(x16, Wp, None, out, epilogue=hip.EPI_H16, prec=prec, fold_s=fs, fold_t=ft, w_lo=1, **kw)
+        tol = 4 * EPS16[prec]
+        assert torch.allclose(out.float(), want, rtol=tol, atol=2 * tol), list(kw)
+    # patch loader
+    size, patch, B, T, Dp = 64, 16, 2, 3, 128
+    g = size // patch
+    n, K = g * g, 3 * patch * patch
+    x = rnd((B, 3, T, size, size), 1.0, 51).to(d)
+    Wf = rnd((Dp, K), K ** -0.5, 52).to(d)
+    hi, lo = _hi_lo(Wf, dt)
+    bias, pos, tim = rnd((Dp,), 1, 53).to(d), rnd((n + 1, Dp), 1, 54).to(d), rnd((T, Dp), 1, 55).to(d)
+    Xo = torch.zeros(B * T * (n + 1), Dp, device=d)
+    hip.gemm(None, torch.cat([hi, lo], 1).contiguous(), bias, Xo, epilogue=hip.EPI_F32_PATCH, prec=prec, pos=pos, time=tim, n_patches=n, T=T,
+             M=B * T * n, frames=x, frame_size=size, patch=patch, w_lo=1)
+    frames = x.permute(0, 2, 1, 3, 4).reshape(B * T, 3, size, size)
+    cols = frames.view(B * T, 3, g, patch, g, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * T, n, K)
+    ref = cols.to(dt).float() @ (hi.float() + lo.float()).t() + bias + pos[1:].unsqueeze(0) + tim[torch.arange(B * T, device=d) % T].unsqueeze(1)
+    assert torch.allclose(Xo.view(B * T, n + 1, Dp)[:, 1:], ref, rtol=2e-5, atol=2e-5)

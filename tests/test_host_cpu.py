@@ -51,7 +51,7 @@ def test_ctypes_structs_match_header_sizes():
     from gava_clip_amd import hip
     names = {"gava_gemm_args": hip.GemmArgs, "gava_layernorm_args": hip.LayerNormArgs,
              "gava_attention_args": hip.AttentionArgs, "gava_vision_layer": hip.VisionLayer,
-             "gava_vision_model": hip.VisionModel, "gava_text_layer": hip.TextLayer, "gava_text_model": hip.TextModel,
+             "gava_vision_model": hip.VisionModel, "gava_vision_layer8": hip.VisionLayer8, "gava_text_layer": hip.TextLayer, "gava_text_model": hip.TextModel,
              "gava_preprocess_args": hip.PreprocessArgs, "gava_layernorm_bwd_args": hip.LayerNormBwdArgs,
              "gava_attention_bwd_args": hip.AttentionBwdArgs}
     src = '#include <stdio.h>\n#include "gava_hip.h"\nint main(){' + "".join(
