@@ -108,13 +108,27 @@ struct Fold {
   const float* partials = nullptr;                                                        // consumer, no row_stats launch
 };
 
+// the 8-bit side of a GEMM in the w_lo = 2 mode (gava_gemm_args): its own lo product (W8 != NULL) and / or the bf8 copies it
+// leaves for the next one
+struct Lo8 {
+  const void* A8 = nullptr; const void* W8 = nullptr; int exp = 0;    // lda8 = 2 lda, ldw8 = 2 ldw (the kernel's contract)
+  void* out8 = nullptr; long ldo8 = 0; void* x8 = nullptr; long ldx8 = 0;
+};
+
 // w_lo (gava_gemm_args.w_lo = 1): W is packed [W_hi | W_lo]; `ldw` is still given as the row pitch of a plain weight (K columns)
 int gemm_x(int w_lo, const void* A, long lda, const void* W, long ldw, const float* bias, void* out, long ldo, int M, int N, int K,
            int epi, int prec, gava_stream_t s, const float* resid = nullptr, long ldr = 0, int scale_cols = 0,
-           float scale = 1.f, int split_out = 0, void* aux_out = nullptr, const Fold* fold = nullptr, int cu_reserve = 0) {
+           float scale = 1.f, int split_out = 0, void* aux_out = nullptr, const Fold* fold = nullptr, int cu_reserve = 0,
+           const Lo8* l8 = nullptr) {
   gava_gemm_args a{};
   a.w_lo = w_lo ? 1 : 0;
   if (w_lo) ldw *= 2;
+  if (l8) {
+    if (l8->W8) {   // the 16-bit loop reads the W_hi half of the [W_hi | W_lo] rows, the 8-bit loop W8
+      a.w_lo = 2; a.A8 = l8->A8; a.lda8 = 2 * lda; a.W8 = l8->W8; a.ldw8 = 2 * ldw; a.w8_exp = l8->exp;
+    }
+    a.out8 = l8->out8; a.ldo8 = l8->ldo8; a.x8_out = l8->x8; a.ld_x8 = l8->ldx8;
+  }
   a.cu_reserve = cu_reserve;
   if (fold) {
     a.x16_out = fold->x16; a.ld_x16 = fold->ld_x16; a.rowsum_out = fold->rowsum; a.rowsum_reduced = fold->reduced;
@@ -137,6 +151,7 @@ struct VisionWs {
   void* CLSPOST; float* PROJ;
   void* XNC; void* QC; void* MIXC; void* HIDC;   // last block: CLS rows only
   float* RSUM; float* STATS;                     // LayerNorm folding: row-sum partials [R][D/64][2], (mean, rstd) [R up to 256][2]
+  void* Xn8; void* HID8;                         // w_lo = 2: bf8 copies of Xn / HID, rows 2D / 2F bytes apart
   size_t total;
 };
 
@@ -200,6 +215,8 @@ VisionWs carve_vision(const gava_vision_model* m, void* ws, size_t cap) {
     w.RSUM = (float*)c.take(per_slot > reduced ? per_slot : reduced);
   }
   w.STATS = (float*)c.take((R + 255) / 256 * 256 * 8);
+  w.Xn8 = m->w_lo == 2 ? c.take((size_t)R * 2 * D) : nullptr;
+  w.HID8 = m->w_lo == 2 ? c.take((size_t)R * 2 * F) : nullptr;
   w.total = (c.off + 255) & ~(size_t)255;
   return w;
 }
@@ -270,6 +287,8 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
   // weight-lo pass (gava_vision_model.w_lo): every weight below except the *_split ones is [W_hi | W_lo], 2x the columns
   const int wl = m->w_lo ? 1 : 0, WL = wl ? 2 : 1;
   if (wl && saved_x) return GAVA_EINVAL;
+  // w_lo = 2: the LayerNorm-folded qkv / fc1 GEMMs and fc2 run their lo product at 8 bits (shapes the persistent kernel takes)
+  const bool l8 = m->w_lo == 2 && m->layer8 && pr == GAVA_PREC_F16 && D % 256 == 0 && F % 256 == 0;
   const char* h16 = nullptr; (void)h16;
 
   // ---- embedding (VitaCLIP_vision_encoder.py:105-113)
@@ -365,11 +384,13 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
     };
     if (!fold1 && !(i == 0 && pre_fused)) TRY(ln(w.X, D, nullptr, L.ln1_g, L.ln1_b, w.Xn, D, nullptr, 0, R, D, pr, stream));
     const unsigned short* sk = (const unsigned short*)w.SIDEKV;
+    const gava_vision_layer8* L8 = l8 ? &m->layer8[i] : nullptr;
     if (not_last) {
       if (fold1) TRY(mark(GAVA_PROBE_QKV, i, 0));     // the folded form only: the instantiation bench.py's table names
       if (fold1) {
-        Fold c = consume(L.qkv_fold_s, L.qkv_fold_t);
-        TRY(gemm_x(wl, w.Xn, D, L.w_qkv_fold, D, nullptr, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, &c, resv));
+        Fold c = consume(L8 ? L8->qkv_fold_s8 : L.qkv_fold_s, L.qkv_fold_t);
+        Lo8 lo; if (L8) { lo.A8 = w.Xn8; lo.W8 = L8->w_qkv_fold8; lo.exp = L8->qkv_fold_exp; }
+        TRY(gemm_x(wl, w.Xn, D, L.w_qkv_fold, D, nullptr, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, &c, resv, L8 ? &lo : nullptr));
       } else
       TRY(gemm_x(wl, w.Xn, D, L.w_qkv, D, L.b_qkv, w.QKV, 3 * D, R, 3 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, D, 0.125f, 0, nullptr, nullptr, resv));
       if (fold1) TRY(mark(GAVA_PROBE_QKV, i, 1));
@@ -388,12 +409,14 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       }
       TRY(mark(GAVA_PROBE_OUT, i, 0));
       if (fold2) {
-        TRY(gemm_x(wl, w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
+        Lo8 po; if (L8) { po.x8 = w.Xn8; po.ldx8 = 2 * D; }      // out_proj: 16-bit lo product, bf8 copy of x16 for fc1
+        TRY(gemm_x(wl, w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce, 0, L8 ? &po : nullptr));
         TRY(mark(GAVA_PROBE_OUT, i, 1));
         if (!skip_stats && !fused) TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
-        Fold c = consume(L.fc1_fold_s, L.fc1_fold_t);
+        Fold c = consume(L8 ? L8->fc1_fold_s8 : L.fc1_fold_s, L.fc1_fold_t);
+        Lo8 lo; if (L8) { lo.A8 = w.Xn8; lo.W8 = L8->w_fc1_fold8; lo.exp = L8->fc1_fold_exp; lo.out8 = w.HID8; lo.ldo8 = 2 * F; }
         TRY(mark(GAVA_PROBE_FC1, i, 0));
-        TRY(gemm_x(wl, w.Xn, D, L.w_fc1_fold, D, nullptr, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, &c));
+        TRY(gemm_x(wl, w.Xn, D, L.w_fc1_fold, D, nullptr, w.HID, F, R, F, D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, &c, 0, L8 ? &lo : nullptr));
         TRY(mark(GAVA_PROBE_FC1, i, 1));
       } else {
         TRY(gemm_x(wl, w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D));
@@ -404,12 +427,16 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
         TRY(mark(GAVA_PROBE_FC1, i, 1));
       }
       TRY(mark(GAVA_PROBE_FC2, i, 0));
+      // fc2: 8-bit lo product when fc1 left the bf8 copy of its output (HID8); its own x16 gets a bf8 copy for the next qkv
+      Lo8 f2; const bool f2_8 = L8 && fold2;
+      if (f2_8) { f2.A8 = w.HID8; f2.W8 = L8->w_fc28; f2.exp = L8->fc2_exp; }
       if (fold1_next) {
-        TRY(gemm_x(wl, w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce));
+        if (L8) { f2.x8 = w.Xn8; f2.ldx8 = 2 * D; }
+        TRY(gemm_x(wl, w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce, 0, L8 ? &f2 : nullptr));
         TRY(mark(GAVA_PROBE_FC2, i, 1));
         if (!skip_stats && !fused) TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
       } else {
-        TRY(gemm_x(wl, w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D));
+        TRY(gemm_x(wl, w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, nullptr, 0, f2_8 ? &f2 : nullptr));
         TRY(mark(GAVA_PROBE_FC2, i, 1));
       }
       folded_in = fold1_next;
@@ -419,9 +446,10 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       // needed for every token, queries / out_proj / MLP only for the B*T CLS rows: same results,
       // 1/197 of the row work.
       if (fold1) {   // norm1 folded into the K/V GEMM: Xn holds the 16-bit copy of the un-normalised stream
-        Fold c = consume(L.qkv_fold_s + D, L.qkv_fold_t + D);
+        Fold c = consume((L8 ? L8->qkv_fold_s8 : L.qkv_fold_s) + D, L.qkv_fold_t + D);
+        Lo8 lo; if (L8) { lo.A8 = w.Xn8; lo.W8 = (const char*)L8->w_qkv_fold8 + (size_t)D * 4 * D; lo.exp = L8->qkv_fold_exp; }
         TRY(gemm_x(wl, w.Xn, D, (const unsigned short*)L.w_qkv_fold + (long)D * WL * D, D, nullptr, (unsigned short*)w.QKV + D, 3 * D, R, 2 * D, D,
-                 GAVA_EPI_H16, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, &c, resv));
+                 GAVA_EPI_H16, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, &c, resv, L8 ? &lo : nullptr));
       } else {
         TRY(gemm_x(wl, w.Xn, D, wqkv + (long)D * WL * D, D, L.b_qkv + D, (unsigned short*)w.QKV + D, 3 * D, R, 2 * D, D, GAVA_EPI_H16, pr, stream, nullptr, 0, 0, 1.f, 0, nullptr, nullptr, resv));
       }

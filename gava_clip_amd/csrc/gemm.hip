@@ -34,6 +34,9 @@
 #define GAVA_V3_PRIO 1
 #endif
 
+#ifndef GAVA_L8_SCHED
+#define GAVA_L8_SCHED 1
+#endif
 namespace {
 
 #ifdef GAVA_ENABLE_ABLATE
@@ -77,6 +80,12 @@ struct GemmParams {
   // weight-lo pass (gava_gemm_args.w_lo).  1: W rows are [W_hi | W_lo], the k-loop runs 2 K / BK stages and the A operand
   // wraps after nka = K / BK of them
   int w_lo, nka;
+  // 2 (persistent 256^2 kernel, L8 instantiations): after the 16-bit stages nk8 = K / 128 stages of the 8-bit lo product:
+  // A8 = bf8 rows of A (2 lda bytes apart), W8 = e4m3 rows of 2^w8_exp W_lo (2 ldw bytes apart); scale8 = the E8M0 byte
+  // 127 - w8_exp in every byte (the block-scaled MFMA multiplies the W8 operand by 2^-w8_exp)
+  const unsigned char* A8; const unsigned char* W8; int nk8; unsigned scale8;
+  unsigned char* out8; long ldo8;   // L8, 16-bit-output epilogues: bf8 copy of the output rows
+  unsigned char* x8; long ldx8;     // L8, producers: bf8 copy of x16
 };
 
 static __device__ __forceinline__ float aux_up(unsigned short u, int f16) {
@@ -433,7 +442,15 @@ int launch_tile(GemmParams gp, int epi, hipStream_t s) {
 // of stage g+2 behind the LDS-DMA of stage g+1 and wait with vmcnt(1): fc2 0.586 vs 0.570 ms, forward 22.02 vs 21.75 ms, slower;
 // removed.  Its first version aborted the process: an asm load whose destination the compiler considers dead lands later in a
 // register that holds something else by then - an asynchronous destination needs a register live for as long as loads fly.)
-template <class P, int EPI, bool RES, bool SPLIT, bool FOLD = false, bool ALIGN = false>
+// L8 (round 4, fp16 operands): the weight-lo product at 8 bits.  After the nk 16-bit stages of a tile come nk8 = K / 128 stages
+// whose LDS image has the SAME shape (256 rows x 128 bytes per operand, same swizzles, same fragment reads: a lane's two 16-byte
+// chunks are now 32 k-values of an 8-bit row instead of 2 x 8 of a 16-bit one - the k order inside an MFMA is free as long as
+// both operands use the same one), multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 (32 per stage at 8 passes = the matrix-pipe
+// time of a 16-bit stage for twice the k) into the SAME accumulators: the W8 operand (e4m3) carries 2^w8_exp W_lo, the
+// instruction's E8M0 scale takes the factor back.  The epilogues also write bf8 copies of their outputs (out8 / x8) for the next
+// L8 GEMM.  L8 = 1: only those copies (a producer whose own lo product is 16-bit); L8 = 2: copies + the 8-bit stages, nk8 >= 1
+// (the tile switch then only happens in the 8-bit loop: one copy of that code per wave half instead of two).
+template <class P, int EPI, bool RES, bool SPLIT, bool FOLD = false, bool ALIGN = false, int L8 = 0>
 __global__ __launch_bounds__(512, 2)
 void gemm256_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NW = 8;
@@ -495,7 +512,8 @@ void gemm256_kernel(const GemmParams p) {
   const int my_tiles = my_tiles_;
   if (my_tiles == 0) return;
   const int nk = p.w_lo == 1 ? 2 * p.nka : p.nka;
-  const int G = my_tiles * nk;
+  const int nk8 = L8 == 2 ? p.nk8 : 0, NT = nk + nk8;    // stages per tile
+  const int G = my_tiles * NT;
   auto tile_coords = [&](int j, int& m0, int& n0) {
     if (ALIGN) {
       // (taking an XCD's blocks last-to-first, so that the rows the previous kernel wrote last - what the Infinity Cache still holds
@@ -516,7 +534,8 @@ void gemm256_kernel(const GemmParams p) {
     n0 = (chunk * p.sn + rr / sm) * BN;
   };
 
-  unsigned src[PPW];   // 32-bit element offsets from p.A / p.W (host guarantees they fit)
+  unsigned src[PPW];   // 32-bit BYTE offsets from p.A / p.W (host guarantees they fit): base + zext(offset) is the LDS-DMA's
+                       // scalar-base + 32-bit-lane-offset addressing form - no 64-bit address arithmetic, no address register pairs
   auto set_src = [&](int m0, int n0) {
     // the lane-dependent terms are recomputed per tile (a few dozen VALU) instead of being hoisted out of the tile loop:
     // hoisted they cost 35 VGPRs, the FOLD kernels then spill, and a spill reload waits on vmcnt, i.e. on the whole
@@ -534,24 +553,33 @@ void gemm256_kernel(const GemmParams p) {
 #ifdef GAVA_EXP_OPERAND_L2   // experiment builds (results WRONG): every tile reads the SAME A rows (1) and / or W rows (2), so that
         if (p.pair_sleep & 1) gm = row;   // operand stays in L2 - what the k-loop would run at without fabric misses on it
 #endif
-        src[i] = (unsigned)gm * (unsigned)p.lda + chunk * 8;
+        src[i] = ((unsigned)gm * (unsigned)p.lda + chunk * 8) * 2u;
       } else {
         const int chunk = (ln & 7) ^ (NAT ? ((row >> 1) & 7) : (((row >> 1) & 1) | (((row >> 4) & 3) << 1)));
-        src[i] = (unsigned)(n0 + row) * (unsigned)p.ldw + chunk * 8;
+        src[i] = ((unsigned)(n0 + row) * (unsigned)p.ldw + chunk * 8) * 2u;
 #ifdef GAVA_EXP_OPERAND_L2
-        if (p.pair_sleep & 2) src[i] = (unsigned)row * (unsigned)p.ldw + chunk * 8;
+        if (p.pair_sleep & 2) src[i] = ((unsigned)row * (unsigned)p.ldw + chunk * 8) * 2u;
 #endif
       }
     }
   };
   auto piece = [&](int slot, int kt, int i) {
     if (i < PPW / 2 && kt >= p.nka) kt -= p.nka;    // w_lo: the second half of the k-loop re-reads A
-    __builtin_amdgcn_global_load_lds(GLB_PTR((i < PPW / 2 ? p.A : p.W) + (size_t)(src[i] + (unsigned)(kt * BK))),
+    __builtin_amdgcn_global_load_lds(GLB_PTR(reinterpret_cast<const char*>(i < PPW / 2 ? p.A : p.W) + (size_t)(src[i] + (unsigned)(kt * BK * 2))),
                                      LDS_PTR(void, smem + slot * STAGE + (wave + i * NW) * 1024), 16, 0, 0);
   };
   auto stage = [&](int g, int kt) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) piece(g & 1, kt, i);
+  };
+  // L8: the same pieces of the 8-bit operands.  Their rows are 2 lda / 2 ldw BYTES apart - the byte pitch of the 16-bit
+  // operands (host contract) - so src[] serves both phases unchanged: piece i of 8-bit stage k8 sits at the byte offset of
+  // the 16-bit piece of stage k8 from the other base pointer
+  auto stage8 = [&](int g, int k8) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR((i < PPW / 2 ? p.A8 : p.W8) + (size_t)(src[i] + (unsigned)(k8 * 128))),
+                                       LDS_PTR(void, smem + (g & 1) * STAGE + (wave + i * NW) * 1024), 16, 0, 0);
   };
   // fold block of tile `tj` at (mm0, nn0); fold_stats holds tiles_m*256 rows (host contract)
   auto fold_fetch = [&](int tj, int mm0, int nn0) {
@@ -707,10 +735,12 @@ void gemm256_kernel(const GemmParams p) {
 #endif
 
   for (int j = 0; j < my_tiles; ++j) {
-    for (int kt = 0; kt < nk; ++kt) {
-      const int g = j * nk + kt;
+    // what every stage starts with: this wave's operand pieces (and what else it has in flight) have landed, the barrier makes
+    // the other waves' pieces visible and frees the other ring slot
+    auto stage_head = [&](int kt) {
       if (stamp) { const unsigned long long t = clock64(); if (in_epi) tE += t - ts; else tC += t - ts; ts = t; in_epi = false; }
-      if (counted == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+      if (counted == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE + 8) : "memory");    // L8: + one out8 store per row group
+      else if (counted == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
       else if (counted == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NSTORE <= 63 ? 2 * NSTORE : 0) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       counted = 0;
@@ -722,28 +752,38 @@ void gemm256_kernel(const GemmParams p) {
 #endif
       // every wave has left the previous tile's epilogue: its row-sum partials are complete in LDS
       if (X16_STAGE && p.rowsum_reduced && kt == 0 && j > 0) flush_rowsum(m0p, n0p);
-      // LDS-DMA issue is expensive (~100+ cycles per 1 KiB piece beside running MFMAs): the two waves
-      // that share a SIMD (w and w+4) issue their 8 pieces half an iteration apart, so one of them
-      // always feeds the matrix pipe.  Waves 0-3 issue here, waves 4-7 after the second MFMA group.
-      auto issue_next = [&]() {
-        if (g + 1 < G) {
-          if (kt + 1 < nk) {
+    };
+    // LDS-DMA issue is expensive (~100+ cycles per 1 KiB piece beside running MFMAs): the two waves
+    // that share a SIMD (w and w+4) issue their 8 pieces half an iteration apart, so one of them
+    // always feeds the matrix pipe.  Waves 0-3 issue at the top of a stage, waves 4-7 after the second MFMA group.
+    // kt: stage of this tile, 0 .. NT-1 (L8: the 8-bit stages follow the nk 16-bit ones)
+    auto issue_next = [&](int kt, bool in_hi) {
+      const int g = j * NT + kt;
+      if (g + 1 < G) {
+        if ((L8 == 2 && in_hi) || kt + 1 < NT) {
+          if (L8 != 2 || (in_hi && kt + 1 < nk)) {
             stage(g + 1, kt + 1);
-            // partials mode: the next tile's partials are fetched three stages before the end of this tile, reduced one
-            // stage later (below) and published by the barrier of the last stage - before this tile's epilogue starts
-            if (CAN_FOLD && p.fpart && kt == nk - 3 && j + 1 < my_tiles) {
-              tile_coords(j + 1, m0n, n0n);
-              fold_fetch(j + 1, m0n, n0n);
-            }
           } else {
-            tile_coords(j + 1, m0n, n0n);
-            set_src(m0n, n0n);
-            stage(g + 1, 0);
-            if (!(CAN_FOLD && p.fpart)) fold_fetch(j + 1, m0n, n0n);
+            stage8(g + 1, kt + 1 - nk);
           }
+          // partials mode: the next tile's partials are fetched three stages before the end of this tile, reduced one
+          // stage later (below) and published by the barrier of the last stage - before this tile's epilogue starts
+          if (CAN_FOLD && p.fpart && kt == NT - 3 && j + 1 < my_tiles) {
+            tile_coords(j + 1, m0n, n0n);
+            fold_fetch(j + 1, m0n, n0n);
+          }
+        } else {
+          tile_coords(j + 1, m0n, n0n);
+          set_src(m0n, n0n);
+          stage(g + 1, 0);
+          if (!(CAN_FOLD && p.fpart)) fold_fetch(j + 1, m0n, n0n);
         }
-      };
-      if (wave < 4) issue_next();
+      }
+    };
+    for (int kt = 0; kt < nk; ++kt) {
+      const int g = j * NT + kt;
+      stage_head(kt);
+      if (wave < 4) issue_next(kt, true);
       const char* cur = smem + (g & 1) * STAGE;
       s16x8_t wf0[4], wf1[4], a00[4], a01[4], a10[4], a11[4];
 #pragma unroll
@@ -768,7 +808,7 @@ void gemm256_kernel(const GemmParams p) {
       __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // a00 x wf0
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // wf1, a10
       __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // a01 x wf0
-      if (wave >= 4) issue_next();
+      if (wave >= 4) issue_next(kt, true);
 #pragma unroll
       for (int i = 0; i < 4; ++i) a11[i] = *reinterpret_cast<const s16x8_t*>(cur + a_off + (4 + i) * 2048 + a_k1);
 #pragma unroll
@@ -781,7 +821,64 @@ void gemm256_kernel(const GemmParams p) {
         for (int jj = 0; jj < 4; ++jj) acc[4 + i][jj] = P::mfma(wf1[jj], a11[i], acc[4 + i][jj]);
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);   // a11
       __builtin_amdgcn_sched_group_barrier(0x008, 32, 1);  // a10 x wf1, a11 x wf1
-      if (CAN_FOLD && p.fpart && kt == nk - 2 && j + 1 < my_tiles) fold_reduce(j + 1);   // its fetch was waited for at this stage's start
+      if (CAN_FOLD && p.fpart && kt == NT - 2 && j + 1 < my_tiles) fold_reduce(j + 1);   // its fetch was waited for at this stage's start
+    }
+    if (L8 == 2) {
+      // the 8-bit lo stages (a loop of their own: one loop with both bodies made hipcc rotate the accumulators through scratch).
+      // 128 k-values per row; lane (fr, fg) multiplies chunks fg and 4 + fg of its rows (the same LDS reads as the two k-halves
+      // of a 16-bit stage), W8 (e4m3, scaled) as the MFMA's A operand, A8 (bf8) as its B operand
+      for (int kt = nk; kt < NT; ++kt) {
+        const int g = j * NT + kt;
+        stage_head(kt);
+        if (wave < 4) issue_next(kt, false);
+        const char* cur = smem + (g & 1) * STAGE;
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        typedef int i32x8_t __attribute__((ext_vector_type(8)));
+        i32x8_t w8[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const i32x4_t lo = *reinterpret_cast<const i32x4_t*>(cur + w_off + jj * WJ + w_k0);
+          const i32x4_t hi = *reinterpret_cast<const i32x4_t*>(cur + w_off + jj * WJ + w_k1);
+          w8[jj] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const i32x4_t lo = *reinterpret_cast<const i32x4_t*>(cur + a_off + i * 2048 + a_k0);
+          const i32x4_t hi = *reinterpret_cast<const i32x4_t*>(cur + a_off + i * 2048 + a_k1);
+          const i32x8_t a8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8[jj], a8, acc[i][jj], 0 /* e4m3 */, 1 /* bf8 */, 0,
+                                                                          (int)p.scale8, 0, 0x7f7f7f7f);
+          if (i == 3) {
+            // pin the first 16 MFMAs in front of the branch below: hipcc otherwise sinks them behind it (their results are next
+            // used an iteration later), next to the other 16 - with all eight A fragments (64 registers) live at once
+            asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+                              "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]),
+                              "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
+#if GAVA_L8_SCHED
+            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);   // w8, a8 of row group 0
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#endif
+            if (wave >= 4) issue_next(kt, false);
+          }
+        }
+#if GAVA_L8_SCHED
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+#endif
+        if (CAN_FOLD && p.fpart && kt == NT - 2 && j + 1 < my_tiles) fold_reduce(j + 1);
+      }
     }
 
     if (stamp) { const unsigned long long t = clock64(); tC += t - ts; ts = t; in_epi = true; }
@@ -892,6 +989,15 @@ void gemm256_kernel(const GemmParams p) {
               *reinterpret_cast<uint4*>(o + 2 * p.N + 8 * h) = H;
             }
           } else {
+            if (L8 && p.out8) {   // bf8 copy of the row segment: the A8 operand of the next GEMM's 8-bit lo product
+              unsigned r8[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                r8[q] = __builtin_amdgcn_cvt_pk_bf8_f32(v[4 * q], v[4 * q + 1], 0u, false);
+                r8[q] = __builtin_amdgcn_cvt_pk_bf8_f32(v[4 * q + 2], v[4 * q + 3], r8[q], true);
+              }
+              *reinterpret_cast<uint4*>(p.out8 + orow * p.ldo8 + nb0) = make_uint4(r8[0], r8[1], r8[2], r8[3]);
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               const uint2 x = pack4<P>(v[8 * h], v[8 * h + 1], v[8 * h + 2], v[8 * h + 3]);
@@ -950,6 +1056,16 @@ void gemm256_kernel(const GemmParams p) {
           const uint4 d = *reinterpret_cast<const uint4*>(xs + row * XS_PITCH + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
           const int mm = m0 + wr * 128 + i * 16 + row;
           if (mm < p.M) *reinterpret_cast<uint4*>(p.x16 + (long)mm * p.ldx16 + n0 + wc * 64 + (lane & 7) * 8) = d;
+          if (L8 && p.x8 && mm < p.M) {   // bf8 copy of the same 8 values (fp16 operands only)
+            const unsigned dw[4] = {d.x, d.y, d.z, d.w};
+            unsigned r8[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              r8[q] = __builtin_amdgcn_cvt_pk_bf8_f32(P::up((unsigned short)dw[2 * q]), P::up((unsigned short)(dw[2 * q] >> 16)), 0u, false);
+              r8[q] = __builtin_amdgcn_cvt_pk_bf8_f32(P::up((unsigned short)dw[2 * q + 1]), P::up((unsigned short)(dw[2 * q + 1] >> 16)), r8[q], true);
+            }
+            *reinterpret_cast<uint2*>(p.x8 + (long)mm * p.ldx8 + n0 + wc * 64 + (lane & 7) * 8) = make_uint2(r8[0], r8[1]);
+          }
         }
       }
       // next tile: its residual rows go straight into the accumulators just freed (all 32 loads in flight
@@ -982,6 +1098,7 @@ void gemm256_kernel(const GemmParams p) {
     // over the next wait (ragged tiles store fewer, and the accumulator-residual loads add to the count:
     // those cases fall back to vmcnt(0)).
     counted = (full && !ACC_RES && !(ABLATE & 4) && !(EPI == GAVA_EPI_F32 && p.x16)) ? ((EPI == GAVA_EPI_H16_QGELU && p.aux_out) ? 2 : 1) : 0;
+    if (L8 && p.out8 && counted) counted = counted == 1 ? 3 : 0;
     m0p = m0; n0p = n0;
     m0 = m0n; n0 = n0n;
   }
@@ -1038,6 +1155,32 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
       const int units = ((gp.tiles_m + a_sm - 1) / a_sm) * (gp.tiles_n / gp.sn);
       const int rounds_aligned = (units + 7) / 8, rounds_plain = ((gp.n_tiles + 7) / 8 + per_xcd - 1) / per_xcd;
       if (rounds_aligned <= rounds_plain) { align = true; gp.sm = a_sm; }
+    }
+  }
+  // the 8-bit lo product / the bf8 copies: fp16 operands, the four per-block GEMMs of the vision tower in the forms the
+  // inference driver launches them (LayerNorm-folded consumers, residual producers); anything else is rejected
+  if (gp.w_lo == 2 || gp.out8 || gp.x8) {
+    if constexpr (std::is_same<P, PrecF16>::value) {
+      if (KERN != 3 || gp.split_out) return GAVA_EINVAL;
+      const bool lo8 = gp.w_lo == 2;
+      if (epi == GAVA_EPI_H16 && (gp.fstats || gp.fpart) && !gp.x8 && lo8)
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_H16, false, false, true, false, 2>), grid, block, 0, s, gp);
+      else if (epi == GAVA_EPI_H16_QGELU && (gp.fstats || gp.fpart) && !gp.x8 && !gp.aux_out && lo8)
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_H16_QGELU, false, false, true, false, 2>), grid, block, 0, s, gp);
+      else if (epi == GAVA_EPI_F32 && gp.resid && !gp.out8 && align && lo8)
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, true, false, false, true, 2>), grid, block, 0, s, gp);
+      else if (epi == GAVA_EPI_F32 && gp.resid && !gp.out8 && align && !lo8)
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, true, false, false, true, 1>), grid, block, 0, s, gp);
+      else if (epi == GAVA_EPI_F32 && gp.resid && !gp.out8 && lo8)
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, true, false, false, false, 2>), grid, block, 0, s, gp);
+      else if (epi == GAVA_EPI_F32 && gp.resid && !gp.out8)
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, true, false, false, false, 1>), grid, block, 0, s, gp);
+      else
+        return GAVA_EINVAL;
+      GAVA_CHECK_LAUNCH();
+      return GAVA_OK;
+    } else {
+      return GAVA_EINVAL;
     }
   }
 #define GAVA_LAUNCH(EPI, RES, SPLIT) hipLaunchKernelGGL((gemm256_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp)
@@ -1372,6 +1515,11 @@ int launch_pair(GemmParams gp, hipStream_t s) {
 template <class P>
 int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   static const int variant = getenv("GAVA_GEMM_VARIANT") ? atoi(getenv("GAVA_GEMM_VARIANT")) : 0;
+  if (gp.w_lo == 2 || gp.out8 || gp.x8) {   // only the persistent 256^2 kernel implements these; never fall back silently
+    const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
+    if (gp.kernel == GAVA_KERNEL_PAIR || gp.N % 256 || !fits || gp.frames || gp.clips) return GAVA_EINVAL;
+    return launch_256<P, 3>(gp, epi, s);
+  }
   // fp32-output GEMMs with the heavy epilogue (residual stream, folding producers): the two-workgroups-per-CU kernel can
   // be named explicitly (gava_gemm_args.kernel) or switched on for big M with GAVA_GEMM_VARIANT=4
   {
@@ -1428,6 +1576,12 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   if (a->w_lo < 0 || a->w_lo > 2) return GAVA_EINVAL;
   if (a->ldw % 8 || a->ldw < (a->w_lo == 1 ? 2 : 1) * (int64_t)a->K) return GAVA_EINVAL;
   if (a->w_lo && (a->kernel == GAVA_KERNEL_PAIR || a->epilogue == GAVA_EPI_H16_QGELU_BWD)) return GAVA_EINVAL;
+  if (a->w_lo == 2 && (!a->A8 || !a->W8 || a->K % 128 || a->lda8 != 2 * a->lda || a->ldw8 != 2 * a->ldw ||
+                       (((uintptr_t)a->A8 | (uintptr_t)a->W8) & 15) || a->w8_exp < -100 || a->w8_exp > 100)) return GAVA_EINVAL;
+  if ((a->w_lo == 2 || a->out8 || a->x8_out) && a->prec != GAVA_PREC_F16) return GAVA_EINVAL;
+  if (a->out8 && ((a->epilogue != GAVA_EPI_H16 && a->epilogue != GAVA_EPI_H16_QGELU) || a->split_out || a->ldo8 % 16 ||
+                  a->ldo8 < a->N || ((uintptr_t)a->out8 & 15))) return GAVA_EINVAL;
+  if (a->x8_out && (!a->x16_out || a->ld_x8 % 8 || a->ld_x8 < a->N || ((uintptr_t)a->x8_out & 7))) return GAVA_EINVAL;
   if (!patch_direct && (a->lda % 8 || a->lda < a->K)) return GAVA_EINVAL;
   if (patch_direct && (a->patch <= 0 || a->frame_size % a->patch || 3 * a->patch * a->patch > a->K ||
                        (a->frame_size / a->patch) * (a->frame_size / a->patch) != a->n_patches ||
@@ -1473,6 +1627,10 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.kernel = a->kernel;
   gp.pair_delay = 0; gp.pair_sleep = 0;
   gp.w_lo = a->w_lo; gp.nka = a->K / BK;
+  gp.A8 = (const unsigned char*)a->A8; gp.W8 = (const unsigned char*)a->W8;
+  gp.nk8 = a->w_lo == 2 ? a->K / 128 : 0;
+  gp.scale8 = 0x01010101u * (unsigned)(127 - a->w8_exp);
+  gp.out8 = (unsigned char*)a->out8; gp.ldo8 = a->ldo8; gp.x8 = (unsigned char*)a->x8_out; gp.ldx8 = a->ld_x8;
 #ifdef GAVA_ENABLE_ABLATE   // timing-probe builds only (tools/ab_build.sh NAME -DGAVA_ENABLE_ABLATE): results are WRONG by design
   static const int ablate = getenv("GAVA_GEMM_ABLATE") ? atoi(getenv("GAVA_GEMM_ABLATE")) : 0;
   gp.ablate = ablate;

@@ -86,8 +86,8 @@ class VisionModel(C.Structure):
 
 
 class VisionLayer8(C.Structure):
-    _fields_ = [(n, _vp) for n in ("w_qkv8", "w_out8", "w_fc18", "w_fc28", "w_qkv_fold8", "w_fc1_fold8")] + \
-               [(n, C.c_int) for n in ("qkv_exp", "out_exp", "fc1_exp", "fc2_exp", "qkv_fold_exp", "fc1_fold_exp")]
+    _fields_ = [(n, _vp) for n in ("w_qkv_fold8", "w_fc1_fold8", "w_fc28", "qkv_fold_s8", "fc1_fold_s8")] + \
+               [(n, C.c_int) for n in ("qkv_fold_exp", "fc1_fold_exp", "fc2_exp")]
 
 
 class TextLayer(C.Structure):
@@ -319,6 +319,25 @@ def split_pack_weight(w, prec):
     hi = convert_h16(w, prec)
     lo = convert_h16(w - hi.float(), prec)
     return torch.cat([hi, hi, lo], dim=1).contiguous()
+
+
+def pack_w8(w, prec):
+    """The 8-bit lo operand of a weight (gava_gemm_args.w_lo = 2): (hi16, W8, exp, row sums) with hi16 = h16(w), W8 = e4m3 bytes
+    of 2^exp (w - hi16) in rows 4K bytes apart (K used), exp chosen so that the largest |w - hi16| lands in [128, 256), and
+    the fp32 row sums of hi16 + 2^-exp W8."""
+    import math
+    w = w.detach().float().contiguous()
+    hi = convert_h16(w, prec)
+    lo = (w - hi.float()).cpu()
+    mx = float(lo.abs().max())
+    e = 7 - int(math.floor(math.log2(mx))) if mx > 0 else 0
+    e = max(-100, min(100, e))
+    q = (lo * (2.0 ** e)).to(torch.float8_e4m3fn)          # OCP e4m3 (gfx950), round to nearest even, on the host
+    N, K = w.shape
+    w8 = torch.zeros(N, 4 * K, dtype=torch.uint8)
+    w8[:, :K] = q.view(torch.uint8)
+    s8 = (hi.float().cpu().double() + q.to(torch.float32).double() * (2.0 ** -e)).sum(1).float()
+    return hi, w8.to(w.device), e, s8.to(w.device).contiguous()
 
 
 def convert_h16(x, prec):

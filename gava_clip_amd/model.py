@@ -506,9 +506,13 @@ class _HipHost:
                    lnpost_g=K(self._f32(v.ln_post.weight)), lnpost_b=K(self._f32(v.ln_post.bias)),
                    w_proj=K(hip.split_pack_weight(v.proj.detach().float().t(), self.prec)))
         layers = (hip.VisionLayer * sh["layers"])()
+        layers8 = (hip.VisionLayer8 * sh["layers"])() if (w_lo == 2 and self.fold_layernorm) else None
         for i, blk in enumerate(v.blocks):
             a, s = blk.attn, blk.summary_attn_layer
             L = layers[i]
+            if layers8 is not None:
+                _, w8, e8, _s = hip.pack_w8(blk.mlp.fc2.weight, self.prec)
+                layers8[i].w_fc28, layers8[i].fc2_exp = K(w8), e8
             L.w_qkv = K(h16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)))
             L.b_qkv = K(self._f32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)))
             L.w_out, L.b_out = K(h16(a.out_proj.weight)), K(self._f32(a.out_proj.bias))
@@ -525,6 +529,11 @@ class _HipHost:
                                                                      blk.mlp.fc1.bias.detach().float(), blk.norm2)):
                     gam, bet = nrm.weight.detach().float(), nrm.bias.detach().float()
                     wf = h16(w0 * gam)
+                    if layers8 is not None:      # the 8-bit lo operand of the folded weight (gava_vision_layer8)
+                        _, w8, e8, s8 = hip.pack_w8(w0 * gam, self.prec)
+                        setattr(layers8[i], f"w_{tag}_fold8", K(w8))
+                        setattr(layers8[i], f"{tag}_fold_s8", K(s8))
+                        setattr(layers8[i], f"{tag}_fold_exp", e8)
                     setattr(L, f"w_{tag}_fold", K(wf))
                     # ([W_hi | W_lo]: the row sum over both halves = the sum of the weight the kernel multiplies by)
                     setattr(L, f"{tag}_fold_s", K(wf.float().sum(1).contiguous()))
@@ -545,7 +554,8 @@ class _HipHost:
             L.local_prompts = K(self._f32(blk.local_prompts[0]))
             L.global_prompts = K(self._f32(v.global_prompts[i]))
         if w_lo:
-            packed.update(vis_wlo=vis, vis_layers_wlo=layers, w_sqkv_wlo=w_sqkv_t, w_sout_wlo=w_sout_t, b_sqkv_wlo=b_sqkv_t)
+            packed.update(vis_wlo=vis, vis_layers_wlo=layers, w_sqkv_wlo=w_sqkv_t, w_sout_wlo=w_sout_t, b_sqkv_wlo=b_sqkv_t,
+                          vis_layers8=layers8)
         else:
             packed.update(vis=vis, vis_layers=layers, w_sqkv=w_sqkv_t, w_sout=w_sout_t, b_sqkv=b_sqkv_t)
 
@@ -628,7 +638,11 @@ class _HipHost:
             setattr(m, k, val)
         m.time_embed = C.c_void_p(te.data_ptr())
         m.layer = C.cast(pk["vis_layers_wlo" if wl else "vis_layers"], C.POINTER(hip.VisionLayer))
-        m.w_lo = 1 if wl else 0
+        m.w_lo = wl
+        if wl == 2 and pk.get("vis_layers8") is not None:
+            m.layer8 = C.cast(pk["vis_layers8"], C.c_void_p)
+        elif wl == 2:
+            m.w_lo = 1            # no folded weights packed (fold_layernorm off): every lo product stays 16-bit
         if clips is not None:
             m.clips, m.clip_lut = hip.ptr(desc), hip.ptr(lut)
         nbytes = lib.gava_vision_workspace_bytes(C.byref(m))

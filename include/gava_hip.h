@@ -142,8 +142,10 @@ typedef struct {
    *   w_lo = 2: the lo product at 8 bits on the block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4: twice the 16-bit
    *             rate): after the K-deep 16-bit loop, K more columns with A8 = bf8 (e5m2) copy of A, bytes [M][lda8], and
    *             W8 = e4m3 rows [N][ldw8] holding 2^w8_exp * W_lo (the MFMA's E8M0 scale operand takes the 2^-w8_exp back, so
-   *             both products share the accumulators).  W stays [N][K] = W_hi.  K % 128 == 0, lda8 / ldw8 % 16 == 0;
-   *             the persistent 256 x 256 kernel only (rejected elsewhere, never replaced).
+   *             both products share the accumulators).  W stays [N][K] = W_hi.  K % 128 == 0; the 8-bit rows keep the BYTE
+   *             pitch of their 16-bit twins, lda8 == 2 lda and ldw8 == 2 ldw (the kernel then addresses both phases with one
+   *             set of offsets; half of each 8-bit row's pitch is unused); the persistent 256 x 256 kernel only (rejected
+   *             elsewhere, never replaced).
    * Producers of a w_lo = 2 operand: out8 (EPI_H16 / EPI_H16_QGELU) = bf8 copy of the 16-bit output rows, bytes [M][ldo8];
    * x8_out (EPI_F32 with x16_out) = bf8 copy of x16_out, bytes [M][ld_x8].  bf8 = the fp16 value rounded to 2 mantissa
    * bits (fp16 operands only). */
@@ -257,18 +259,22 @@ typedef struct {
   /* Weight-lo pass (gava_gemm_args.w_lo), inference drivers only (gava_vision_forward; the training drivers reject it).
    * w_lo = 1: w_patch and every 16-bit weight of gava_vision_layer except the *_split ones are packed [W_hi | W_lo] with
    * twice the columns ([3D][2D], [F][2D], [D][2F], ...; the folded copies too, their fold_s = row sums of hi + lo).
-   * w_lo = 2: as 1, and the four full-width GEMMs of a block (qkv, out_proj, fc1, fc2 over all B*T*(n+1) rows) run their
-   * lo product at 8 bits from the layer's *8 weights (gava_vision_layer8), activations leaving their producers with a bf8 copy. */
+   * w_lo = 2 (fp16 operands): packed as 1, and the LayerNorm-folded qkv / fc1 GEMMs and fc2 over all B*T*(n+1) rows run their
+   * lo product at 8 bits from the layer's *8 weights (gava_vision_layer8), their A operands leaving the producers (out_proj,
+   * fc2, fc1) with a bf8 copy; every other GEMM (and every shape the persistent kernel does not take) as in w_lo = 1. */
   int w_lo;
   const struct gava_vision_layer8* layer8;     /* host array [layers], w_lo = 2 only */
 } gava_vision_model;
 
-/* e4m3 rows of 2^exp * W_lo for the 8-bit lo product (gava_gemm_args.W8 / w8_exp): [3D][D], [D][D], [F][D], [D][F] bytes;
- * qkv / fc1: of the LayerNorm-folded weight when the layer carries one (blocks whose norm is folded), else of the plain one. */
+/* e4m3 rows of 2^exp * W_lo for the 8-bit lo product (gava_gemm_args.W8 / w8_exp) of the GEMMs that run it - the
+ * LayerNorm-folded qkv and fc1 (W_lo of the folded weight h16(gamma * W)) and fc2: [3D] / [F] rows of D bytes, [D] rows of F
+ * bytes, each row 4x its length apart (ldw8 = 2 ldw, and the 16-bit weight rows are [W_hi | W_lo], gava_vision_model.w_lo).
+ * *_fold_s8[n] = sum_k (W_hi[n][k] + 2^-exp W8[n][k]), the row sums of the weight these GEMMs multiply by.
+ * out_proj keeps the 16-bit lo product (its A operand, the attention output, has no 8-bit copy). */
 typedef struct gava_vision_layer8 {
-  const void* w_qkv8; const void* w_out8; const void* w_fc18; const void* w_fc28;
-  const void* w_qkv_fold8; const void* w_fc1_fold8;
-  int qkv_exp, out_exp, fc1_exp, fc2_exp, qkv_fold_exp, fc1_fold_exp;
+  const void* w_qkv_fold8; const void* w_fc1_fold8; const void* w_fc28;
+  const float* qkv_fold_s8; const float* fc1_fold_s8;
+  int qkv_fold_exp, fc1_fold_exp, fc2_exp;
 } gava_vision_layer8;
 
 /* CLIPVisionEncoder.forward (VitaCLIP_vision_encoder.py:102-132).

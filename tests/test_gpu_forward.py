@@ -130,7 +130,7 @@ def test_c1_other_seeds_normwise_bar(golden_dir, name):
     assert rel_to_max(lg, g["logits"]) < 1e-3
 
 
-WLO_MODES = ["fp16+wlo"]
+WLO_MODES = ["fp16+wlo", "fp16+wlo8"]
 
 
 @pytest.mark.parametrize("mode", WLO_MODES)

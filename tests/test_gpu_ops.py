@@ -643,3 +643,96 @@ def test_gemm_weight_lo_with_folded_layernorm_and_patch_loader(prec):
     cols = frames.view(B * T, 3, g, patch, g, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * T, n, K)
     ref = cols.to(dt).float() @ (hi.float() + lo.float()).t() + bias + pos[1:].unsqueeze(0) + tim[torch.arange(B * T, device=d) % T].unsqueeze(1)
     assert torch.allclose(Xo.view(B * T, n + 1, Dp)[:, 1:], ref, rtol=2e-5, atol=2e-5)
+
+
+def _bf8(t):
+    """bf8 (e5m2) bytes of a tensor, rounded to nearest even on the host - what the kernels' v_cvt_pk_bf8_f32 produces."""
+    return t.float().cpu().to(torch.float8_e5m2)
+
+
+def _a8_rows(a16, pitch):
+    M, K = a16.shape
+    buf = torch.zeros(M, pitch, dtype=torch.uint8)
+    buf[:, :K] = _bf8(a16).view(torch.uint8)
+    return buf
+
+
+@pytest.mark.parametrize("M,N,K,kind", [(45056, 768, 3072, "fc2"), (20000, 2304, 768, "qkv"), (300, 3072, 768, "fc1"), (5000, 768, 768, "fc2")])
+def test_gemm_weight_lo_pass_at_8_bits(M, N, K, kind):
+    """gava_gemm_args.w_lo = 2: after the K-deep fp16 loop the persistent kernel runs K / 128 stages of
+    v_mfma_scale_f32_16x16x128_f8f6f4 on A8 = bf8(A) and W8 = e4m3(2^e (W - W_hi)) into the same accumulators.  Checked
+    against exactly that arithmetic on the host (A16 . W_hi^T + A8 . W8^T 2^-e in fp64), then against A16 . W^T (the point of
+    it: the weight rounding is gone up to the 8-bit lo's own ~6 %).  fc2 / out form: fp32 residual epilogue with the x16 + x8
+    copies; qkv / fc1 form: LayerNorm-folded consumer with the out8 copy."""
+    d = dev()
+    prec, dt = hip.PREC_F16, torch.float16
+    Wf = rnd((N, K), K ** -0.5, 2).to(d)
+    hi, w8, e8, s8 = hip.pack_w8(Wf, prec)
+    hl = torch.cat([hi, (Wf - hi.float()).to(dt)], 1).contiguous()                  # the [W_hi | W_lo] rows the model packs
+    w8deq = w8[:, :K].view(torch.float8_e4m3fn).float().double() * 2.0 ** -e8
+    if kind == "fc2":
+        A = rnd((M, K), 1.0, 1).to(d).to(dt)
+        A8 = _a8_rows(A, 2 * K).to(d)
+        bias = rnd((N,), 0.5, 3).to(d)
+        X0 = rnd((M, N), 1.0, 4).to(d)
+        X = X0.clone()
+        Mp = (M + 255) // 256 * 256
+        x16 = torch.zeros(Mp, N, dtype=dt, device=d)
+        x8 = torch.zeros(Mp, 2 * N, dtype=torch.uint8, device=d)
+        part = torch.zeros(Mp + 32, 4, 2, dtype=torch.float32, device=d)
+        hip.gemm(A, hl, bias, X, epilogue=hip.EPI_F32, prec=prec, resid=X, w_lo=2, K=K, A8=A8, W8=w8, w8_exp=e8,
+                 x16_out=x16, rowsum_out=part, rowsum_reduced=True, x8_out=x8)
+        want = X0.double() + A.double() @ hi.double().t() + _bf8(A).float().double().to(d) @ w8deq.t() + bias.double()
+        assert torch.allclose(X.double(), want, rtol=2e-5, atol=2e-5)
+        exact = X0.double() + A.double() @ Wf.double().t() + bias.double()
+        Y = X0.clone()
+        hip.gemm(A, hi.contiguous(), bias, Y, epilogue=hip.EPI_F32, prec=prec, resid=Y)
+        e_lo, e_plain = float((X.double() - exact).abs().max()), float((Y.double() - exact).abs().max())
+        print(f"\n[w_lo=2 {M}x{N}x{K}] max error vs A16.W^T: 8-bit lo {e_lo:.2e}, plain fp16 weights {e_plain:.2e}")
+        assert e_lo < 0.2 * e_plain
+        assert torch.equal(x16[:M], X.to(dt))
+        assert torch.equal(x8[:M, :N].cpu(), _bf8(x16[:M]).view(torch.uint8))
+        with pytest.raises(hip.GavaError):      # the 8-bit rows must keep the byte pitch of their 16-bit twins
+            hip.gemm(A, hl, bias, X, epilogue=hip.EPI_F32, prec=prec, resid=X, w_lo=2, K=K, A8=A8[:, :K].contiguous(), W8=w8, w8_exp=e8)
+        return
+    # folded consumers: x16 = the un-normalised stream, W = gamma-folded weight
+    D = K
+    X = (rnd((M, D), 1.0, 4) + 0.3).to(d)
+    x16 = X.to(dt)
+    A8 = _a8_rows(x16, 2 * D).to(d)
+    Mp = (M + 255) // 256 * 256
+    part = torch.zeros(Mp + 32, 4, 2, dtype=torch.float32, device=d)
+    for sl in range(D // 256):
+        seg = X[:, sl * 256:(sl + 1) * 256]
+        part[:M, sl, 0], part[:M, sl, 1] = seg.sum(1), (seg * seg).sum(1)
+    mean, var = X.mean(1), X.var(1, unbiased=False)
+    stats = torch.zeros(Mp, 2, device=d); stats[:M, 0], stats[:M, 1] = mean, (var + 1e-5).rsqrt()
+    ft = rnd((N,), 0.3, 8).to(d)
+    epi = hip.EPI_H16 if kind == "qkv" else hip.EPI_H16_QGELU
+    acc = x16.double() @ hi.double().t() + _bf8(x16).float().double().to(d) @ w8deq.t()
+    want = (stats[:M, 1:2].double() * (acc - stats[:M, 0:1].double() * s8.double()) + ft.double()).float()
+    if epi == hip.EPI_H16_QGELU:
+        want = want * torch.sigmoid(1.702 * want)
+    tol = 4 * EPS16[prec]
+    for kw in (dict(fold_stats=stats), dict(fold_partials=part)):
+        out = torch.zeros(M, N, dtype=dt, device=d)
+        out8 = torch.zeros(M, 2 * N, dtype=torch.uint8, device=d)
+        hip.gemm(x16, hl, None, out, epilogue=epi, prec=prec, fold_s=s8, fold_t=ft, w_lo=2, K=K, A8=A8, W8=w8, w8_exp=e8, out8=out8, **kw)
+        assert torch.allclose(out.float(), want, rtol=tol, atol=2 * tol), list(kw)
+        got8 = out8[:, :N].cpu().view(torch.float8_e5m2).float()
+        assert torch.allclose(got8, out.float().cpu(), rtol=0.13, atol=1e-4)      # bf8: 2 mantissa bits
+
+
+def test_gemm_weight_lo_8_bit_rejects_what_it_does_not_take():
+    d = dev()
+    A = rnd((512, 256), 1.0, 1).to(d).half()
+    Wf = rnd((256, 256), 0.06, 2).to(d)
+    hi, w8, e8, s8 = hip.pack_w8(Wf, hip.PREC_F16)
+    hl = torch.cat([hi, (Wf - hi.float()).half()], 1).contiguous()
+    A8 = _a8_rows(A, 512).to(d)
+    out = torch.zeros(512, 256, dtype=torch.float16, device=d)
+    with pytest.raises(hip.GavaError):       # plain 16-bit-output GEMM (no LayerNorm fold): no 8-bit instantiation
+        hip.gemm(A, hl, None, out, epilogue=hip.EPI_H16, prec=hip.PREC_F16, w_lo=2, K=256, A8=A8, W8=w8, w8_exp=e8)
+    with pytest.raises(hip.GavaError):       # bf16 operands
+        hip.gemm(A.bfloat16(), hl.bfloat16(), None, torch.zeros(512, 256, device=d), epilogue=hip.EPI_F32, prec=hip.PREC_BF16,
+                 resid=torch.zeros(512, 256, device=d), w_lo=2, K=256, A8=A8, W8=w8, w8_exp=e8)
