@@ -38,7 +38,7 @@ def source_hash() -> str:
     h.update(" ".join(FLAGS).encode())
     for name in sorted(os.listdir(CSRC)):
         p = os.path.join(CSRC, name)
-        if os.path.isfile(p):
+        if os.path.isfile(p) and (name in SOURCES or name.endswith(".h")):      # stray editor / backup files do not count
             h.update(name.encode() + b"\0")
             with open(p, "rb") as f:
                 h.update(f.read())

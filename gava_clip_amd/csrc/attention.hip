@@ -7,7 +7,7 @@
 // single pass: no online rescaling.  Two kernels: attention_kernel, one 4-wave workgroup per problem (two per CU), and
 // attention_persist_kernel for the vision blocks at 209..224 keys, one 8-wave workgroup per CU walking the problems with
 // K/V double-buffered and the next problem staged by the wave that has no query tiles (see there).
-// Round-2 measurements behind the present form (tools/attn_stamps.py, tools/r2_attn_ab.sh; ViT-B/16 T=8 B=64, 0.200 ms
+// Round-2 measurements behind the present form (tools/attn_stamps.py, tools/archive/r2_attn_ab.sh; ViT-B/16 T=8 B=64, 0.200 ms
 // before): loads alone 0.072 ms, compute alone 0.158 ms, so the load phase was only partly hidden by the CU's second
 // workgroup -> persistent + prefetch; per-tile mask branches cost 750 of a pair's 5900 cycles -> branch-free masks on the
 // tiles that can need them; 56 LDS-DMA issues per problem take ~3000 cycles to be accepted -> one loader wave; the kernel

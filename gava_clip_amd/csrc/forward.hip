@@ -169,7 +169,10 @@ int patch_operand(const gava_vision_model* m, const float* x, void* scratch, int
                   gava_gemm_args* a) {
   static const int forced = getenv("GAVA_PATCH_DIRECT") ? atoi(getenv("GAVA_PATCH_DIRECT")) : -1;
   // (P % 8 != 0 - ViT-L/14 - has no float4 form of the in-loop loader: eight scalar loads per chunk; it stays two-pass)
-  const bool direct = forced >= 0 ? forced != 0 : (m->clips == nullptr && m->P % 8 == 0);
+  // the in-loop loader reads the frames with float4 loads: a clip tensor whose storage is not 16-byte aligned (a view at an odd
+  // offset) or whose rows are not a multiple of 4 floats takes the two-pass form, which has no such requirement
+  const bool aligned = m->clips != nullptr || ((((uintptr_t)x) & 15) == 0 && m->size % 4 == 0);
+  const bool direct = forced >= 0 ? (forced != 0 && aligned) : (m->clips == nullptr && m->P % 8 == 0 && aligned);
   a->lda = Kp; a->frame_size = m->size; a->patch = m->P;
   if (direct) {
     a->A = nullptr; a->frames = m->clips ? nullptr : x; a->clips = m->clips; a->clip_lut = m->clip_lut;

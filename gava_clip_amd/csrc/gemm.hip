@@ -73,8 +73,11 @@ struct GemmParams {
   unsigned long long* dbg;  // debug only: per-wave segment cycle sums (gava_debug_set_buffer)
   int cu_reserve;   // persistent kernels: CUs left out of the grid (gava_gemm_args.cu_reserve)
   int kernel;       // gava_gemm_args.kernel
-  int pair_delay;   // experiment builds: start delay of a CU's second workgroup, 10 ns ticks
-  int pair_sleep;   // experiment builds: s_sleep units after every epilogue chunk
+  // experiment builds only (each switch has its own field; all 0 in the product library)
+  int pair_delay;   // -DGAVA_ENABLE_ABLATE / -DGAVA_EXP_STAGGER: start delay of a CU's second workgroup / of the late slots, 10 ns ticks
+  int pair_sleep;   // -DGAVA_ENABLE_ABLATE: s_sleep units after every epilogue chunk of the pair kernel
+  int stagger_mode; // -DGAVA_EXP_STAGGER: which workgroups start late (0 odd slots, 1 (slot & 3) * delay / 2, 2 XCDs 4-7)
+  int operand_l2;   // -DGAVA_EXP_OPERAND_L2: bit 0 every tile reads the same A rows, bit 1 the same W rows (results wrong)
   int ablate;   // timing probes, always 0 unless built with -DGAVA_ENABLE_ABLATE: 1 = no staging loads after the prologue,
                 // 2 = no LDS reads/MFMA, 4 = no epilogue
   // weight-lo pass (gava_gemm_args.w_lo).  1: W rows are [W_hi | W_lo], the k-loop runs 2 K / BK stages and the A operand
@@ -551,14 +554,14 @@ void gemm256_kernel(const GemmParams p) {
         int gm = m0 + row;
         gm = gm < p.M ? gm : p.M - 1;
 #ifdef GAVA_EXP_OPERAND_L2   // experiment builds (results WRONG): every tile reads the SAME A rows (1) and / or W rows (2), so that
-        if (p.pair_sleep & 1) gm = row;   // operand stays in L2 - what the k-loop would run at without fabric misses on it
+        if (p.operand_l2 & 1) gm = row;   // operand stays in L2 - what the k-loop would run at without fabric misses on it
 #endif
         src[i] = ((unsigned)gm * (unsigned)p.lda + chunk * 8) * 2u;
       } else {
         const int chunk = (ln & 7) ^ (NAT ? ((row >> 1) & 7) : (((row >> 1) & 1) | (((row >> 4) & 3) << 1)));
         src[i] = ((unsigned)(n0 + row) * (unsigned)p.ldw + chunk * 8) * 2u;
 #ifdef GAVA_EXP_OPERAND_L2
-        if (p.pair_sleep & 2) src[i] = ((unsigned)row * (unsigned)p.ldw + chunk * 8) * 2u;
+        if (p.operand_l2 & 2) src[i] = ((unsigned)row * (unsigned)p.ldw + chunk * 8) * 2u;
 #endif
       }
     }
@@ -727,8 +730,8 @@ void gemm256_kernel(const GemmParams p) {
   if (GAVA_V3_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #ifdef GAVA_EXP_STAGGER   // experiment builds (-DGAVA_EXP_STAGGER, nothing inside the loops): a start offset between workgroups,
   {                       // GAVA_PAIR_DELAY x 10 ns; GAVA_STAGGER_MODE 0: odd slots of every XCD late, 1: (slot & 3) * delay / 2, 2: XCDs 4-7 late
-    const unsigned long long d = p.pair_sleep == 1 ? (unsigned long long)(slot & 3) * p.pair_delay / 2
-                               : p.pair_sleep == 2 ? (xcd >= 4 ? p.pair_delay : 0) : ((slot & 1) ? p.pair_delay : 0);
+    const unsigned long long d = p.stagger_mode == 1 ? (unsigned long long)(slot & 3) * p.pair_delay / 2
+                               : p.stagger_mode == 2 ? (xcd >= 4 ? p.pair_delay : 0) : ((slot & 1) ? p.pair_delay : 0);
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(32);
   }
@@ -1119,6 +1122,32 @@ void gemm256_kernel(const GemmParams p) {
 }
 
 
+// The aligned walk's super-tile height (in m-tiles) for an fp32-output GEMM of tiles_m x tiles_n tiles on `blocks` workgroups, or
+// 0 when the plain walk is taken: sn must divide the n-tiles, every CU of the grid is used and the block count per XCD does
+// not exceed the rounds of the plain walk.  GAVA_TILE_ALIGN=0: never (A/B).
+int aligned_walk_sm(int tiles_m, int tiles_n, int sn, int blocks, int avail) {
+  static const bool align_ok = !(getenv("GAVA_TILE_ALIGN") && getenv("GAVA_TILE_ALIGN")[0] == '0');
+  if (!align_ok || blocks != avail || tiles_n % sn) return 0;
+  const int per_xcd = blocks / 8, a_sm = per_xcd / sn;
+  if (a_sm < 1) return 0;
+  const int units = ((tiles_m + a_sm - 1) / a_sm) * (tiles_n / sn);
+  const int rounds_aligned = (units + 7) / 8, rounds_plain = ((tiles_m * tiles_n + 7) / 8 + per_xcd - 1) / per_xcd;
+  return rounds_aligned <= rounds_plain ? a_sm : 0;
+}
+
+// CUs of the current device in whole XCD multiples, and the grid of a persistent launch
+int persistent_cus() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    n_cu = prop.multiProcessorCount / 8 * 8;
+    if (n_cu <= 0) n_cu = 8;
+  }
+  return n_cu;
+}
+
 template <class P, int KERN>
 int launch_256(GemmParams gp, int epi, hipStream_t s) {
   gp.tiles_m = (gp.M + 255) / 256;
@@ -1127,35 +1156,24 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
   gp.sn = gp.tiles_n < 4 ? gp.tiles_n : 4;
   gp.sm = 32 / gp.sn;
   if (gp.sm > gp.tiles_m) gp.sm = gp.tiles_m;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GAVA_ELAUNCH;
-    n_cu = prop.multiProcessorCount / 8 * 8;
-    if (n_cu <= 0) n_cu = 8;
-  }
+  const int n_cu = persistent_cus();
+  if (n_cu < 0) return GAVA_ELAUNCH;
   // GAVA_CU_RESERVE (diagnostics, tools/side_probe.py) overrides what the caller asks for
   static const int forced = getenv("GAVA_CU_RESERVE") ? atoi(getenv("GAVA_CU_RESERVE")) : -1;
   const int reserve = forced >= 0 ? forced : (gp.cu_reserve > 0 ? gp.cu_reserve : 0);
   const int avail = n_cu - reserve > 8 ? (n_cu - reserve) / 8 * 8 : 8;
   const int blocks = gp.n_tiles < avail ? (gp.n_tiles + 7) / 8 * 8 : avail;
   // (A W-stationary tile walk - an XCD stays on one chunk of weight panels and walks down the M-groups - was measured in
-  // round 2, tools/r2_walk.sh: fabric fetch unchanged (FETCH_SIZE 421 -> 432 MB per fc1 launch), 3-6 % slower; removed.)
+  // round 2, tools/archive/r2_walk.sh: fabric fetch unchanged (FETCH_SIZE 421 -> 432 MB per fc1 launch), 3-6 % slower; removed.)
   dim3 grid(blocks), block(512);
   // aligned walk (fp32-output kernels): blocks of sm x sn tiles with sm * sn <= workgroups per XCD, taken when sn divides the
   // n-tiles, every XCD is full and the block count per XCD does not exceed the rounds of the plain walk; GAVA_TILE_ALIGN=0: off (A/B)
-  static const bool align_ok = !(getenv("GAVA_TILE_ALIGN") && getenv("GAVA_TILE_ALIGN")[0] == '0');
   bool align = false;
   // (the LayerNorm-folded consumers were measured with it too: fc1 0.5313 vs 0.5322 ms, no gain - their A operand is served by
   // the Infinity Cache whatever the walk - so only the fp32-output kernels carry the instantiation)
-  if (align_ok && epi == GAVA_EPI_F32 && blocks == avail && gp.tiles_n % gp.sn == 0) {
-    const int per_xcd = blocks / 8, a_sm = per_xcd / gp.sn;
-    if (a_sm >= 1) {
-      const int units = ((gp.tiles_m + a_sm - 1) / a_sm) * (gp.tiles_n / gp.sn);
-      const int rounds_aligned = (units + 7) / 8, rounds_plain = ((gp.n_tiles + 7) / 8 + per_xcd - 1) / per_xcd;
-      if (rounds_aligned <= rounds_plain) { align = true; gp.sm = a_sm; }
-    }
+  if (epi == GAVA_EPI_F32) {
+    const int a_sm = aligned_walk_sm(gp.tiles_m, gp.tiles_n, gp.sn, blocks, avail);
+    if (a_sm) { align = true; gp.sm = a_sm; }
   }
   // the 8-bit lo product / the bf8 copies: fp16 operands, the four per-block GEMMs of the vision tower in the forms the
   // inference driver launches them (LayerNorm-folded consumers, residual producers); anything else is rejected
@@ -1521,7 +1539,7 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
     return launch_256<P, 3>(gp, epi, s);
   }
   // fp32-output GEMMs with the heavy epilogue (residual stream, folding producers): the two-workgroups-per-CU kernel can
-  // be named explicitly (gava_gemm_args.kernel) or switched on for big M with GAVA_GEMM_VARIANT=4
+  // be named explicitly (gava_gemm_args.kernel)
   {
     const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
     const long tiles128 = (long)((gp.M + 127) / 128) * (gp.N / 256);
@@ -1533,11 +1551,10 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
       return can_256 ? launch_256<P, 3>(gp, epi, s) : GAVA_EINVAL;
     }
     if (gp.kernel != GAVA_KERNEL_AUTO) return GAVA_EINVAL;
-    // Measured in round 3 (profiles/r03_pair_*.txt): the pair kernel does not win - out_proj 0.299 vs 0.276 ms, fc2 0.69 vs 0.575 ms
-    // on the 256^2 kernel; the epilogue of one workgroup does not drain under the k-loop of the other.  It stays selectable
-    // (GAVA_GEMM_VARIANT=4 for whole-forward A/B, gava_gemm_args.kernel for tests) and is NOT taken automatically.
+    // Measured in round 3 (profiles/r03_pair_kernel.txt): the pair kernel does not win - out_proj 0.299 vs 0.276 ms, fc2 0.69 vs
+    // 0.575 ms on the 256^2 kernel; the epilogue of one workgroup does not drain under the k-loop of the other.  It is never taken
+    // automatically and has no environment switch: only gava_gemm_args.kernel = GAVA_KERNEL_PAIR names it (tests, A/B timing).
     (void)tiles128;
-    if (can_pair && variant == 4 && tiles128 >= 1024 && (gp.resid || gp.x16)) return launch_pair<P>(gp, s);
   }
   if (gp.rowsum_reduced || gp.fpart) {   // only the persistent kernels implement these; never fall back silently
     const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
@@ -1566,6 +1583,18 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int gava_gemm_aligned_walk(int M, int N, int cu_reserve) {
+  if (M <= 0 || N <= 0 || N % 256) return 0;
+  const int n_cu = persistent_cus();
+  if (n_cu < 0) return 0;
+  static const int forced = getenv("GAVA_CU_RESERVE") ? atoi(getenv("GAVA_CU_RESERVE")) : -1;
+  const int reserve = forced >= 0 ? forced : (cu_reserve > 0 ? cu_reserve : 0);
+  const int avail = n_cu - reserve > 8 ? (n_cu - reserve) / 8 * 8 : 8;
+  const int tiles_m = (M + 255) / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
+  const int blocks = n_tiles < avail ? (n_tiles + 7) / 8 * 8 : avail;
+  return aligned_walk_sm(tiles_m, tiles_n, tiles_n < 4 ? tiles_n : 4, blocks, avail) ? 1 : 0;
+}
 
 extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   const bool patch_u8 = a && a->epilogue == GAVA_EPI_F32_PATCH && !a->A && !a->frames && a->clips;
@@ -1625,7 +1654,7 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.split_out = a->split_out;
   gp.cu_reserve = a->cu_reserve;
   gp.kernel = a->kernel;
-  gp.pair_delay = 0; gp.pair_sleep = 0;
+  gp.pair_delay = 0; gp.pair_sleep = 0; gp.stagger_mode = 0; gp.operand_l2 = 0;
   gp.w_lo = a->w_lo; gp.nka = a->K / BK;
   gp.A8 = (const unsigned char*)a->A8; gp.W8 = (const unsigned char*)a->W8;
   gp.nk8 = a->w_lo == 2 ? a->K / 128 : 0;
@@ -1639,12 +1668,12 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
 #endif
 #ifdef GAVA_EXP_OPERAND_L2
   static const int opl2_ = getenv("GAVA_OPERAND_L2") ? atoi(getenv("GAVA_OPERAND_L2")) : 0;
-  gp.pair_sleep = opl2_;
+  gp.operand_l2 = opl2_;
 #endif
 #ifdef GAVA_EXP_STAGGER
   static const int pdelay_ = getenv("GAVA_PAIR_DELAY") ? atoi(getenv("GAVA_PAIR_DELAY")) : 0;
   static const int smode_ = getenv("GAVA_STAGGER_MODE") ? atoi(getenv("GAVA_STAGGER_MODE")) : 0;
-  gp.pair_delay = pdelay_; gp.pair_sleep = smode_;
+  gp.pair_delay = pdelay_; gp.stagger_mode = smode_;
 #endif
   gp.dbg = gava::debug_buffer();
   hipStream_t s = (hipStream_t)stream;

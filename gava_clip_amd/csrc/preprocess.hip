@@ -60,9 +60,11 @@ __global__ __launch_bounds__(256) void patchify_kernel(const PatchifyParams p) {
       if (VEC == 4) {
         const float4 q = *reinterpret_cast<const float4*>(plane + e0);
         v[0] = q.x; v[1] = q.y; v[VEC - 2] = q.z; v[VEC - 1] = q.w;
-      } else {
+      } else if (VEC == 2) {
         const float2 q = *reinterpret_cast<const float2*>(plane + e0);
         v[0] = q.x; v[1] = q.y;
+      } else {
+        v[0] = plane[e0];      // VEC == 1: a clip tensor at an odd storage offset (no alignment requirement at all)
       }
     } else {
 #pragma unroll
@@ -73,7 +75,8 @@ __global__ __launch_bounds__(256) void patchify_kernel(const PatchifyParams p) {
     const int px = x0 / p.P, ix = x0 - px * p.P;
     unsigned short* o = orow0 + (long)px * p.ldo + iy * p.P + ix;
     if (VEC == 4) *reinterpret_cast<uint2*>(o) = pack4<Pr>(v[0], v[1], v[VEC - 2], v[VEC - 1]);
-    else *reinterpret_cast<unsigned*>(o) = Pr::cvt2(v[0], v[1]);
+    else if (VEC == 2) *reinterpret_cast<unsigned*>(o) = Pr::cvt2(v[0], v[VEC - 1]);
+    else *o = Pr::cvt(v[0]);
   }
   // zero the K padding of this patch row once (the c == 0 workgroup)
   const int pad = (int)p.ldo - 3 * PP;
@@ -92,20 +95,25 @@ extern "C" int gava_patchify(const gava_patchify_args* a, gava_stream_t stream) 
   if (a->clips && !a->clip_lut) return GAVA_EINVAL;
   if (a->B <= 0 || a->T <= 0 || a->size <= 0 || a->patch <= 0 || a->size % a->patch || a->patch % 2) return GAVA_EINVAL;
   if (a->ldo < 3 * a->patch * a->patch || a->ldo % 8 || ((uintptr_t)a->out & 15)) return GAVA_EINVAL;
-  if (a->x && (((uintptr_t)a->x & 15) || (a->patch % 4 == 0 && a->size % 4))) return GAVA_EINVAL;
+  if (a->x && ((uintptr_t)a->x & 3)) return GAVA_EINVAL;
   PatchifyParams p;
   p.x = a->x; p.clips = a->clips; p.lut = a->clip_lut;
   p.out = (unsigned short*)a->out; p.ldo = a->ldo;
   p.T = a->T; p.size = a->size; p.P = a->patch; p.g = a->size / a->patch;
   dim3 grid(p.g, 3, a->B * a->T), block(256);
-  const bool v4 = a->patch % 4 == 0;
+  // vector width of the fp32 loads: 4 / 2 floats when the patch size, the row length and the clips' address allow it, else
+  // one float at a time (a clip tensor that is a view at an odd offset of a larger storage: slower, never rejected)
+  const bool v4 = a->patch % 4 == 0 && (!a->x || (((uintptr_t)a->x & 15) == 0 && a->size % 4 == 0));
+  const bool v2 = !a->x || (((uintptr_t)a->x & 7) == 0 && a->size % 2 == 0);
   hipStream_t s = (hipStream_t)stream;
   if (a->prec == GAVA_PREC_F16) {
     if (v4) hipLaunchKernelGGL((patchify_kernel<PrecF16, 4>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((patchify_kernel<PrecF16, 2>), grid, block, 0, s, p);
+    else if (v2) hipLaunchKernelGGL((patchify_kernel<PrecF16, 2>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((patchify_kernel<PrecF16, 1>), grid, block, 0, s, p);
   } else if (a->prec == GAVA_PREC_BF16) {
     if (v4) hipLaunchKernelGGL((patchify_kernel<PrecBF16, 4>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((patchify_kernel<PrecBF16, 2>), grid, block, 0, s, p);
+    else if (v2) hipLaunchKernelGGL((patchify_kernel<PrecBF16, 2>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((patchify_kernel<PrecBF16, 1>), grid, block, 0, s, p);
   } else return GAVA_EINVAL;
   if (hipGetLastError() != hipSuccess) return GAVA_ELAUNCH;
   return GAVA_OK;

@@ -22,7 +22,8 @@ EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_text_forward", "gava_similarity_head", "gava_convert_h16", "gava_debug_set_buffer",
            "gava_preprocess_clip", "gava_layernorm_backward", "gava_qgelu_backward", "gava_attention_backward",
            "gava_text_forward_train", "gava_vision_forward_train", "gava_attention_backward_workspace_bytes", "gava_vision_forward_keep", "gava_row_stats",
-           "gava_probe_fc1_enable", "gava_probe_fc1_read", "gava_clip_geometry", "gava_patchify", "gava_attention_f32"]
+           "gava_probe_fc1_enable", "gava_probe_fc1_read", "gava_clip_geometry", "gava_patchify", "gava_attention_f32",
+           "gava_gemm_aligned_walk"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 
@@ -172,8 +173,13 @@ def load():
     # the library reports the hash of the header it was compiled against; the ctypes mirrors in this file follow the header
     # in the tree (tests/test_host_cpu.py compares every struct size with the C compiler's): a stale .so would be called with
     # shifted structs, so it is refused here
-    from .build import abi_hash
-    have, want = lib.gava_abi_version(), abi_hash()
+    from .build import abi_hash, HEADER
+    try:
+        want = abi_hash()
+    except OSError as e:
+        raise GavaError(f"cannot read {os.path.normpath(HEADER)} ({e}): the ctypes mirrors in gava_clip_amd/hip.py are checked against "
+                        "the ABI hash of that header, keep include/gava_hip.h next to the package") from None
+    have = lib.gava_abi_version()
     if have != want:
         raise GavaError(f"{LIB_PATH} was built from another include/gava_hip.h (ABI {have:#x}, header in the tree {want:#x}): "
                         "rebuild with `python -m gava_clip_amd.build --force`")
@@ -209,6 +215,7 @@ def load():
     lib.gava_attention_backward_workspace_bytes.restype = C.c_size_t
     lib.gava_clip_geometry.argtypes = [C.POINTER(ClipDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.gava_clip_geometry.restype = C.c_int
+    lib.gava_gemm_aligned_walk.argtypes, lib.gava_gemm_aligned_walk.restype = [C.c_int, C.c_int, C.c_int], C.c_int
     lib.gava_probe_fc1_enable.argtypes = [C.c_int]
     lib.gava_probe_fc1_read.argtypes = [C.POINTER(C.c_float), C.c_int]
     lib.gava_row_stats.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, _vp]

@@ -353,7 +353,7 @@ class _HipHost:
         self.fold_layernorm = os.environ.get("GAVA_LN_FOLD", "1") != "0"
         self.trim_text_rows = os.environ.get("GAVA_TEXT_TRIM", "1") != "0"   # skip the rows behind the last EOT (see _pack)
         # inference, opt-in: the last block's B*T CLS rows (the only ones that reach the outputs) in split precision.
-        # Measured at c1 (tools/r2_diag.py): video-feature rms error 2.06e-5 with, 2.10e-5 without - the error of the
+        # Measured at c1 (tools/archive/r2_diag.py): video-feature rms error 2.06e-5 with, 2.10e-5 without - the error of the
         # features is made in the fp16 K/V and in the eleven blocks before, not here - so it is off by default.
         self.split_last_block = os.environ.get("GAVA_LAST_SPLIT", "0") != "0"
         self.text_rows_per_prompt = shape.get("L", 77)
@@ -1077,11 +1077,13 @@ class VitaCLIP(nn.Module, _HipHost):
             cls_x, summary = VisionTowerFn.apply(self, x, *[p for _, p in self._vision_trainables()])
         else:
             cls_x, summary = self.encode_video(x, clips=clips)
+        # The all-gather of the clip embeddings goes out on the main stream as soon as the vision tower is enqueued - BEFORE the
+        # join with the text stream, so that it overlaps what is left of the text tower (it does not depend on it).
+        # Under autograd every rank keeps its own clips (the reference's DDP computes the loss on local logits).
+        video = cls_x if cls_x.requires_grad else self._gather(cls_x)
         if text_stream is not None:
             torch.cuda.current_stream(x.device).wait_stream(text_stream)
             text.record_stream(torch.cuda.current_stream(x.device))
-        # under autograd every rank keeps its own clips (the reference's DDP computes the loss on local logits)
-        video = cls_x if cls_x.requires_grad else self._gather(cls_x)
         if torch.is_grad_enabled() and (text.requires_grad or video.requires_grad or self.logit_scale.requires_grad):
             # training: the 2*B*C*E-flop head is traced by torch so that d logits reaches both towers' HIP backward
             logits = self._train_head(video, text, summary, desc_wise)

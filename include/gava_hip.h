@@ -157,6 +157,10 @@ typedef struct {
 #define GAVA_KERNEL_256 3
 #define GAVA_KERNEL_PAIR 4
 int gava_gemm(const gava_gemm_args* a, gava_stream_t stream);
+/* Measurement helper (bench.py names the kernel instantiation a GEMM runs as): 1 when an EPI_F32 GEMM of M x N on the
+ * persistent 256 x 256 kernel of the CURRENT device takes the aligned tile walk (the <..., ALIGN = true> instantiation:
+ * super-tile blocks dealt to the XCDs), 0 when it takes the plain walk.  The same decision gava_gemm makes. */
+int gava_gemm_aligned_walk(int M, int N, int cu_reserve);
 
 /* Row LayerNorm (eps 1e-5, affine) fp32 -> h16 and/or fp32; one wave per row.  Replaces
  * LayerNorm (VitaCLIP_vision_encoder_utils.py:22-28, VitaCLIP_text_encoder.py:19-25).

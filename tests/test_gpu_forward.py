@@ -149,6 +149,47 @@ def test_weight_lo_modes_meet_the_normwise_bar_on_every_c1_seed(golden_dir, name
     assert np.array_equal(lg.argmax(-1), g["logits"].argmax(-1))
 
 
+@pytest.mark.parametrize("name", ["c2_full", "c3_clip0", "c3_full", "c5_clip0", "c5_full"])
+def test_weight_lo_modes_on_the_full_size_fixtures(golden_dir, name):
+    """The other five reference fixtures (full c2 / c3 / c5 batches, clip 0 of c3 and c5) in both weight-lo modes: with the
+    twelve c1 seeds above that is all 17 logit fixtures at norm-wise <= 1e-3 with no expected failure.  One model and one
+    input per fixture, the modes switched on it (set_operand_dtype re-packs the weights)."""
+    from helpers import golden_case
+    path = os.path.join(golden_dir, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{name}.npz not generated")
+    g = np.load(path)
+    cfg, class_file, n_cls, B, wseed, xseed = golden_case(name)
+    m = VitaCLIP(**model_kwargs(cfg, class_file), operand_dtype="fp16")
+    m.load_state_dict(synth_torch_state(cfg, n_cls, wseed), strict=True)
+    m = m.cuda().eval()
+    x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size, seed=xseed)).cuda()
+    for mode in WLO_MODES:
+        m.set_operand_dtype(mode)
+        with torch.no_grad():
+            lg = m(x)[0].cpu().numpy()
+        e_rel, viol = rel_to_max(lg, g["logits"]), mixed_violation(lg, g["logits"])
+        ev = rel_to_max(m.last["video_features"].cpu().numpy(), g["video_features"])
+        agree = int((lg.argmax(-1) == g["logits"].argmax(-1)).sum())
+        print(f"\n[{name}/{mode}] {lg.size} logits: rel-to-max {e_rel:.2e} mixed {viol:.3f} video features {ev:.2e} top-1 agrees on {agree}/{B}")
+        assert e_rel < 1e-3 and viol <= 1.0 and ev < 1e-3
+        assert agree >= B - 1
+
+
+def test_clip_tensor_at_an_odd_storage_offset_is_accepted():
+    """the default patch loader reads the clips with float4 loads; a contiguous view at a 4-byte storage offset must
+    not be rejected - the driver falls back to the two-pass patch matrix (scalar loads), same bits."""
+    m, _ = build(TINY)
+    x = torch.from_numpy(synth.synth_clip(2, TINY.num_frames, TINY.input_size)).cuda()
+    big = torch.empty(x.numel() + 1, dtype=torch.float32, device="cuda")
+    xv = big[1:].view_as(x)
+    xv.copy_(x)
+    assert xv.is_contiguous() and xv.data_ptr() % 16 == 4
+    with torch.no_grad():
+        a, b = m(x)[0], m(xv)[0]
+    assert torch.equal(a, b)
+
+
 def test_forward_is_deterministic_and_batch_invariant():
     """Clips are independent: a clip's logits must not depend on its batch mates, and
     two runs are bit-identical (no atomics anywhere on the path)."""
@@ -487,7 +528,7 @@ def test_c3_c5_full_batch_vs_the_reference(golden_dir, name, cfg_name, cls, n_cl
           f"rel-to-max {e_rel:.2e} mixed {viol:.3f}; video features {ev:.2e} text features {et:.2e}; top-1 agrees on {agree}/32 clips")
     assert viol <= 1.0
     assert e_rel < 1e-3
-    assert ev < 1.5e-3 and et < 2e-5
+    assert ev < 1e-3 and et < 2e-5          # measured 5.0e-4 (c3) / 6.8e-4 (c5): the same 1e-3 as every other fixture
     assert agree >= 31
 
 

@@ -464,8 +464,8 @@ def test_layernorm_fold_with_outlier_channels(mode):
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 768), (4133, 1024, 256), (129, 512, 3072), (7, 768, 128),
                                    (45056, 768, 768), (33001, 768, 3072)])
 def test_gemm_pair_kernel(prec, M, N, K):
-    """The two-workgroups-per-CU 128 x 256 kernel (gava_gemm_args.kernel = GAVA_KERNEL_PAIR; out_proj / fc2 of the vision
-    blocks take it automatically at full size) named explicitly on small, ragged and full-size shapes: plain fp32 output,
+    """The two-workgroups-per-CU 128 x 256 kernel (gava_gemm_args.kernel = GAVA_KERNEL_PAIR: never taken automatically - it
+    measured slower than the 256^2 kernel, DESIGN.md "Round 3") named explicitly on small, ragged and full-size shapes: plain fp32 output,
     fp32 residual (in place and from another buffer with its own stride), and the folding-producer form (16-bit copy +
     per-256-column row sums) - against torch on the same rounded operands, bit for bit against the 256^2 kernel (same
     k order: the two kernels differ in tiling only), rows beyond M untouched."""
