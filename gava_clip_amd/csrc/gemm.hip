@@ -453,9 +453,22 @@ int launch_tile(GemmParams gp, int epi, hipStream_t s) {
 // instruction's E8M0 scale takes the factor back.  The epilogues also write bf8 copies of their outputs (out8 / x8) for the next
 // L8 GEMM.  L8 = 1: only those copies (a producer whose own lo product is 16-bit); L8 = 2: copies + the 8-bit stages, nk8 >= 1
 // (the tile switch then only happens in the 8-bit loop: one copy of that code per wave half instead of two).
-template <class P, int EPI, bool RES, bool SPLIT, bool FOLD = false, bool ALIGN = false, int L8 = 0>
+// PP (round 4): the "ping-pong" k-loop.  A 64-deep k-tile is cut into FOUR phases of 16 MFMAs (one quadrant of
+// the wave's 128 x 64 outputs x K = 64), each { fragment reads of the quadrant | 2 LDS-DMA pieces (one half-tile per phase and
+// workgroup) | counted vmcnt | s_barrier | lgkmcnt(0) | s_setprio 1 | 16 MFMA | s_setprio 0 | s_barrier }, and the two wave
+// groups (waves 0-3 / 4-7: the SIMD partners) run ONE BARRIER APART: while one group's MFMAs hold the matrix pipe its partner
+// issues fragment reads and LDS-DMA (the default loop interleaves loads and MFMAs inside every wave and leaves the SIMD
+// arbitration to the hardware: 64 MFMAs per barrier, a stage of 4.1 k cycles for 2.05 k cycles of MFMA).  A k-tile buffer holds
+// four half-tiles in the order they are consumed, [A0 | W0 | W1 | A1] (128 rows x 128 B each): A half mi = rows wr*128 + mi*64 ..
+// of every row half, W half ni = the rows of every wave's quadrant ni, so that quadrant (mi, ni) reads A half mi and W half ni
+// only, a half-tile is dead after one phase and can be restaged two phases later; half-tiles are staged SIX ahead, one per phase,
+// through the tile switch.  The remap sits on the staging SOURCE rows: the accumulator layout - and with it every epilogue - is
+// the default loop's.  Measured (tools/gemm_vs_vendor.py, non-persistent first version): 4096^3 1264 vs 1122 TF/s, K = 3072 at
+// M = 100864 1165 vs 1108 (vendor 1100).  K % 128 == 0, K >= 256.
+template <class P, int EPI, bool RES, bool SPLIT, bool FOLD = false, bool ALIGN = false, int L8 = 0, bool PP = false>
 __global__ __launch_bounds__(512, 2)
 void gemm256_kernel(const GemmParams p) {
+  static_assert(!(PP && L8 == 2), "the ping-pong loop has no 8-bit stages");
   constexpr int BM = 256, BN = 256, NW = 8;
   constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;   // 32 KiB, 64 KiB
   constexpr int PPW = (BM + BN) / 8 / NW;                            // 8 glds per wave per stage
@@ -545,6 +558,30 @@ void gemm256_kernel(const GemmParams p) {
     // operand prefetch in flight (measured: +9 % per stage)
     int ln = lane;
     if (FOLD || GAVA_V3_RECOMPUTE_SRC) asm volatile("" : "+v"(ln));
+    if (PP) {
+      // src[2 s + i]: piece (wave + 8 i) of half-tile slot s (0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1); lr = the
+      // piece's row in the half-tile.  A half mi holds tile rows (lr >> 6) * 128 + mi * 64 + (lr & 63); W half ni holds, per wave
+      // column block (lr >> 5), the 32 W rows whose fragments quadrant ni multiplies: natural order ni * 32 + (lr & 31), or - the
+      // 16-bit outputs' permuted order, 16 consecutive columns per lane - 16 * ((lr >> 3) & 3) + 8 * ni + (lr & 7).
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int lr = (wave + 8 * i) * 8 + (ln >> 3);
+          if (sl == 0 || sl == 3) {
+            const int mi = sl == 3;
+            int gm = m0 + (lr >> 6) * 128 + mi * 64 + (lr & 63);
+            gm = gm < p.M ? gm : p.M - 1;
+            src[2 * sl + i] = ((unsigned)gm * (unsigned)p.lda + (((ln & 7) ^ ((lr >> 1) & 7)) * 8)) * 2u;
+          } else {
+            const int ni = sl - 1;
+            const int wrow = NAT ? (lr >> 5) * 64 + ni * 32 + (lr & 31) : (lr >> 5) * 64 + 16 * ((lr >> 3) & 3) + 8 * ni + (lr & 7);
+            const int sw = NAT ? ((lr >> 1) & 7) : (((lr >> 1) & 1) | (((lr >> 3) & 3) << 1));
+            src[2 * sl + i] = ((unsigned)(n0 + wrow) * (unsigned)p.ldw + (((ln & 7) ^ sw) * 8)) * 2u;
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int piece = wave + i * NW;                 // 0..31: A rows, 32..63: W rows
@@ -613,6 +650,21 @@ void gemm256_kernel(const GemmParams p) {
   const int w_off = A_BYTES + (NAT ? (wc * 64 + fr) : (wc * 64 + 16 * (fr >> 2) + (fr & 3))) * 128;
   const int a_k0 = (fg ^ swa) << 4, a_k1 = ((4 + fg) ^ swa) << 4;
   const int w_k0 = (fg ^ swb) << 4, w_k1 = ((4 + fg) ^ swb) << 4;
+  // PP: half-tile (k-tile kt of the tile src[] points at, slot sl) into k-tile buffer b; fragment rows inside a half-tile:
+  // A quadrant mi: wr*64 + i'*16 + fr of slot (mi ? 3 : 0); W quadrant ni: wc*32 + jj'*16 + fr (natural) or
+  // wc*32 + 8*(fr>>2) + 4*jj' + (fr&3) (permuted) of slot 1 + ni; every read swizzled by fr >> 1
+  constexpr int HALF = 128 * BK * 2;
+  auto stage_half = [&](int kt, int sl, int b) {
+    const bool is_a = sl == 0 || sl == 3;
+    if (is_a && kt >= p.nka) kt -= p.nka;           // w_lo = 1: the second half of the k-loop re-reads A
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(reinterpret_cast<const char*>(is_a ? p.A : p.W) + (size_t)(src[2 * sl + i] + (unsigned)(kt * BK * 2))),
+                                       LDS_PTR(void, smem + b * STAGE + sl * HALF + (wave + 8 * i) * 1024), 16, 0, 0);
+  };
+  const int pp_a = (wr * 64 + fr) * 128, pp_w = (NAT ? (wc * 32 + fr) : (wc * 32 + 8 * (fr >> 2) + (fr & 3))) * 128;
+  const int pp_k0 = (fg ^ (fr >> 1)) << 4, pp_k1 = ((4 + fg) ^ (fr >> 1)) << 4;
+  constexpr int PP_WJ = NAT ? 2048 : 512;           // LDS byte step between the two W fragments of a quadrant
 
   f32x4_t acc[8][4];
   // residual tile (rows mm0+wr*128+i*16+fr, columns nn0+wc*64+16*fg+4*jj..) straight into accumulator i
@@ -704,7 +756,12 @@ void gemm256_kernel(const GemmParams p) {
     }
   }
   set_src(m0, n0);
-  stage(0, 0);
+  if (PP) {
+#pragma unroll
+    for (int S = 0; S < 6; ++S) stage_half(S >> 2, S & 3, (S >> 2) & 1);     // six half-tiles ahead: k-tile 0 and half of k-tile 1
+  } else {
+    stage(0, 0);
+  }
   if (CAN_FOLD) {
     fold_fetch(0, m0, n0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -713,6 +770,12 @@ void gemm256_kernel(const GemmParams p) {
       __builtin_amdgcn_s_barrier();
     }
     fold_init(0);
+  }
+  if (PP) {
+    // half-tiles 0, 1 (and the residual tile, older) have landed; the barrier publishes them; then group 1 falls one barrier behind
+    if (!CAN_FOLD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
   }
   int counted = 0;   // the next wait may leave this wave's NSTORE (1) or 2*NSTORE (2: pre-activation copy) epilogue stores in flight
   // diagnostic stamps (gava_debug_set_buffer; tools/gemm_stamps.py): cycles in the vmcnt wait, the barrier,
@@ -783,6 +846,95 @@ void gemm256_kernel(const GemmParams p) {
         }
       }
     };
+    if (PP) {
+      // vmcnt(n) for the handful of counts the schedule uses (the immediate must be a literal)
+      auto wait_vm = [&](int n) {
+        if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        else if (n == 8 + NSTORE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NSTORE <= 63 ? 8 + NSTORE : 0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 2 * NSTORE <= 63 ? 8 + 2 * NSTORE : 0) : "memory");
+      };
+      const bool has_next = j + 1 < my_tiles;
+      s16x8_t af[4][2], w0f[2][2], w1f[2][2];      // A fragments of the quadrant row in work, W fragments of quadrant column 0 / 1
+      auto pp_ktile = [&](int kt, auto Bc) {
+        constexpr int B = decltype(Bc)::value;
+        const char* buf = smem + B * STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // ---- load section: the fragments of this phase's quadrant ...
+          if (q == 0) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              w0f[jj][0] = *reinterpret_cast<const s16x8_t*>(buf + 1 * HALF + pp_w + jj * PP_WJ + pp_k0);
+              w0f[jj][1] = *reinterpret_cast<const s16x8_t*>(buf + 1 * HALF + pp_w + jj * PP_WJ + pp_k1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              af[i][0] = *reinterpret_cast<const s16x8_t*>(buf + 0 * HALF + pp_a + i * 2048 + pp_k0);
+              af[i][1] = *reinterpret_cast<const s16x8_t*>(buf + 0 * HALF + pp_a + i * 2048 + pp_k1);
+            }
+          } else if (q == 1) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              w1f[jj][0] = *reinterpret_cast<const s16x8_t*>(buf + 2 * HALF + pp_w + jj * PP_WJ + pp_k0);
+              w1f[jj][1] = *reinterpret_cast<const s16x8_t*>(buf + 2 * HALF + pp_w + jj * PP_WJ + pp_k1);
+            }
+          } else if (q == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              af[i][0] = *reinterpret_cast<const s16x8_t*>(buf + 3 * HALF + pp_a + i * 2048 + pp_k0);
+              af[i][1] = *reinterpret_cast<const s16x8_t*>(buf + 3 * HALF + pp_a + i * 2048 + pp_k1);
+            }
+          }
+          // ... the half-tile six ahead (slots 2, 3 of the next k-tile in phases 0, 1: the other buffer; slots 0, 1 of the
+          // one after in phases 2, 3: this buffer, last read two / three phases ago).  Two k-tiles before the end of the
+          // tile the staging crosses into the next tile: its coordinates and fold block at phase 0, its sources at phase 2.
+          if (kt == nk - 2 && has_next) {
+            if (q == 0) {
+              tile_coords(j + 1, m0n, n0n);
+              if (CAN_FOLD) fold_fetch(j + 1, m0n, n0n);      // 3 more LDS-DMA loads in flight during this k-tile's four phases
+            }
+            if (q == 2) set_src(m0n, n0n);
+          }
+          const int ktt = kt + (q < 2 ? 1 : 2);
+          const bool more = ktt < nk || has_next;
+          if (more) stage_half(ktt < nk ? ktt : ktt - nk, (q + 2) & 3, q < 2 ? (B ^ 1) : B);
+          // ... and the wait that retires what the NEXT phase reads: half-tiles up to "this phase + 2"; the four younger ones
+          // (8 pieces of this wave) stay in flight, plus the fold block's 3 loads while they are younger than the half-tile
+          // waited for, plus - in the first k-tile after an epilogue - that epilogue's stores (counted: exactly NSTORE / 2 NSTORE per wave)
+          if (!more) wait_vm(0);
+          else if (kt == 0 && j > 0 && counted == 0) wait_vm(q == 0 ? 0 : 8);
+          else if (kt == 0 && j > 0) wait_vm(counted == 2 ? 8 + 2 * NSTORE : 8 + NSTORE);
+          else if (CAN_FOLD && kt == nk - 2 && has_next) wait_vm(11);
+          else wait_vm(8);
+          __builtin_amdgcn_s_barrier();
+          // every wave of BOTH groups has left the previous tile's epilogue (group 1 runs a barrier behind): its row-sum partials are complete
+          if (X16_STAGE && p.rowsum_reduced && kt == 0 && q == 1 && j > 0) flush_rowsum(m0p, n0p);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          // ---- MFMA section: quadrant (mi, ni) = (0,0) (0,1) (1,1) (1,0)
+          constexpr int dummy = 0; (void)dummy;
+          const int mi = q >> 1, ni = (q == 1 || q == 2) ? 1 : 0;
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj)
+                acc[mi * 4 + i][ni * 2 + jj] = P::mfma(ni ? w1f[jj][kk] : w0f[jj][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + jj]);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (CAN_FOLD && p.fpart && kt == nk - 1 && q == 1 && has_next) fold_reduce(j + 1);   // fetched a k-tile ago, landed by now
+          __builtin_amdgcn_s_barrier();
+        }
+      };
+      for (int kt = 0; kt < nk; kt += 2) {      // K % 128 == 0: the two k-tile buffers alternate statically
+        pp_ktile(kt, std::integral_constant<int, 0>{});
+        pp_ktile(kt + 1, std::integral_constant<int, 1>{});
+      }
+    } else
     for (int kt = 0; kt < nk; ++kt) {
       const int g = j * NT + kt;
       stage_head(kt);
@@ -1091,7 +1243,7 @@ void gemm256_kernel(const GemmParams p) {
     if (CAN_FOLD && j + 1 < my_tiles) {
       // the next tile's fold block was issued before this epilogue's stores: it has landed once at most those are in flight
       // (partials mode: it landed, and was reduced, two stages ago)
-      if (!p.fpart) {
+      if (!p.fpart && !PP) {     // (PP: the fold block was retired by the counted waits of the k-tile it was fetched in)
         if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE <= 63 ? NSTORE : 0) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -1105,6 +1257,7 @@ void gemm256_kernel(const GemmParams p) {
     m0p = m0; n0p = n0;
     m0 = m0n; n0 = n0n;
   }
+  if (PP && wr == 0) __builtin_amdgcn_s_barrier();     // pairs with group 1's last barrier
   if (X16_STAGE && p.rowsum_reduced) {
     __syncthreads();
     flush_rowsum(m0p, n0p);
@@ -1133,6 +1286,13 @@ int aligned_walk_sm(int tiles_m, int tiles_n, int sn, int blocks, int avail) {
   const int units = ((tiles_m + a_sm - 1) / a_sm) * (tiles_n / sn);
   const int rounds_aligned = (units + 7) / 8, rounds_plain = ((tiles_m * tiles_n + 7) / 8 + per_xcd - 1) / per_xcd;
   return rounds_aligned <= rounds_plain ? a_sm : 0;
+}
+
+// where AUTO takes the ping-pong loop: GAVA_PP = 0 nowhere, 1 wherever an instantiation exists, 2 (default) the residual
+// producers only (out_proj / fc2: measured faster there, K = 3072 by 4 %; the K = 768 consumers are 3-4 % slower on it)
+int pp_mode() {
+  static const int v = getenv("GAVA_PP") ? atoi(getenv("GAVA_PP")) : 2;
+  return v;
 }
 
 // CUs of the current device in whole XCD multiples, and the grid of a persistent launch
@@ -1199,6 +1359,31 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
       return GAVA_OK;
     } else {
       return GAVA_EINVAL;
+    }
+  }
+  // the ping-pong k-loop (template flag PP): named by gava_gemm_args.kernel = GAVA_KERNEL_PP, or taken for the forward's four
+  // per-block GEMMs when GAVA_PP != 0 (default: see pp_default()); K % 128 == 0 and at least four k-tiles
+  {
+    const bool can_pp = gp.K % 128 == 0 && (gp.w_lo == 1 ? 2 : 1) * gp.K >= 256 && !gp.split_out && !gp.aux_out && !gp.aux;
+    const bool want_pp = gp.kernel == GAVA_KERNEL_PP ||
+                         (gp.kernel == GAVA_KERNEL_AUTO && (pp_mode() == 1 || (pp_mode() == 2 && epi == GAVA_EPI_F32 && gp.resid)));
+    if (gp.kernel == GAVA_KERNEL_PP && !can_pp) return GAVA_EINVAL;
+    if (want_pp && can_pp) {
+      bool done = true;
+      if (epi == GAVA_EPI_H16 && (gp.fstats || gp.fpart))
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_H16, false, false, true, false, 0, true>), grid, block, 0, s, gp);
+      else if (epi == GAVA_EPI_H16_QGELU && (gp.fstats || gp.fpart))
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_H16_QGELU, false, false, true, false, 0, true>), grid, block, 0, s, gp);
+      else if (epi == GAVA_EPI_H16)
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_H16, false, false, false, false, 0, true>), grid, block, 0, s, gp);
+      else if (epi == GAVA_EPI_F32 && gp.resid && align)
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, true, false, false, true, 0, true>), grid, block, 0, s, gp);
+      else if (epi == GAVA_EPI_F32 && gp.resid)
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, true, false, false, false, 0, true>), grid, block, 0, s, gp);
+      else
+        done = false;
+      if (done) { GAVA_CHECK_LAUNCH(); return GAVA_OK; }
+      if (gp.kernel == GAVA_KERNEL_PP) return GAVA_EINVAL;      // a named kernel that does not take the call is rejected, never replaced
     }
   }
 #define GAVA_LAUNCH(EPI, RES, SPLIT) hipLaunchKernelGGL((gemm256_kernel<P, EPI, RES, SPLIT>), grid, block, 0, s, gp)
@@ -1546,7 +1731,7 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
     const bool can_pair = !gp.w_lo && epi == GAVA_EPI_F32 && gp.N % 256 == 0 && gp.N <= 1024 && gp.K % 128 == 0 && fits && !gp.frames &&
                           !gp.clips && (gp.rowsum_reduced || !gp.x16);
     if (gp.kernel == GAVA_KERNEL_PAIR) return can_pair ? launch_pair<P>(gp, s) : GAVA_EINVAL;
-    if (gp.kernel == GAVA_KERNEL_256) {
+    if (gp.kernel == GAVA_KERNEL_256 || gp.kernel == GAVA_KERNEL_PP) {
       const bool can_256 = gp.N % 256 == 0 && fits && !gp.frames && !gp.clips;
       return can_256 ? launch_256<P, 3>(gp, epi, s) : GAVA_EINVAL;
     }

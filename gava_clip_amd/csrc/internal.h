@@ -1,6 +1,7 @@
 // internal.h — launchers shared between translation units of libgava_hip.so (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "../../include/gava_hip.h"
 namespace gava {
 int side_ln(const float* gp, const float* lp, const float* cp, const float* summ, const float* gamma,
             const float* beta, void* out, int G, int T, int BT, int D, int prec, hipStream_t s);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAVA_HIP_LIB") or os.path.join(_HERE, "libgava_hip.so")   # env: A/B experiment builds only
 
 PREC_F16, PREC_BF16 = 0, 1
-KERNEL_AUTO, KERNEL_256, KERNEL_PAIR = 0, 3, 4     # gava_gemm_args.kernel
+KERNEL_AUTO, KERNEL_256, KERNEL_PAIR, KERNEL_PP = 0, 3, 4, 5     # gava_gemm_args.kernel
 EPI_H16, EPI_H16_QGELU, EPI_F32, EPI_F32_PATCH, EPI_H16_QGELU_BWD = 0, 1, 2, 3, 4
 PREC_NAMES = {"fp16": PREC_F16, "f16": PREC_F16, "bf16": PREC_BF16}
 PREC_TORCH = {PREC_F16: torch.float16, PREC_BF16: torch.bfloat16}

@@ -156,6 +156,10 @@ typedef struct {
 #define GAVA_KERNEL_AUTO 0
 #define GAVA_KERNEL_256 3
 #define GAVA_KERNEL_PAIR 4
+#define GAVA_KERNEL_PP 5    /* round 4: the persistent 256 x 256 kernel with the "ping-pong" k-loop (four 16-MFMA phases per k-tile,
+                               the two wave groups one barrier apart, half-tiles staged six ahead): EPI_H16 / EPI_H16_QGELU
+                               with the LayerNorm fold, plain EPI_H16, EPI_F32 with a residual (and its producer extras);
+                               N % 256 == 0, K % 128 == 0, K >= 256 */
 int gava_gemm(const gava_gemm_args* a, gava_stream_t stream);
 /* Measurement helper (bench.py names the kernel instantiation a GEMM runs as): 1 when an EPI_F32 GEMM of M x N on the
  * persistent 256 x 256 kernel of the CURRENT device takes the aligned tile walk (the <..., ALIGN = true> instantiation:

@@ -736,3 +736,85 @@ def test_gemm_weight_lo_8_bit_rejects_what_it_does_not_take():
     with pytest.raises(hip.GavaError):       # bf16 operands
         hip.gemm(A.bfloat16(), hl.bfloat16(), None, torch.zeros(512, 256, device=d), epilogue=hip.EPI_F32, prec=hip.PREC_BF16,
                  resid=torch.zeros(512, 256, device=d), w_lo=2, K=256, A8=A8, W8=w8, w8_exp=e8)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 512, 256), (5000, 768, 768), (20000, 2304, 768), (1000, 256, 3072), (70000, 768, 768)])
+def test_gemm_ping_pong_kernel(prec, M, N, K):
+    """GAVA_KERNEL_PP (gemm256_kernel<..., PP>): four 16-MFMA phases per k-tile, the wave groups one barrier apart, half-tiles
+    staged six ahead through the tile switch.  Same k order as the default loop -> bit-identical 16-bit outputs; ragged M, bias,
+    rows beyond M untouched, several tiles per workgroup (M = 70000: 822 tiles on 256 workgroups)."""
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    A = rnd((M, K), 1.0, 1).to(d).to(dt)
+    W = rnd((N, K), K ** -0.5, 2).to(d).to(dt)
+    bias = rnd((N,), 0.5, 3).to(d)
+    out = torch.full((M + 7, N), 3.0, dtype=dt, device=d)
+    hip.gemm(A, W, bias, out, epilogue=hip.EPI_H16, prec=prec, kernel=hip.KERNEL_PP, M=M)
+    ref = A.float() @ W.float().t() + bias
+    tol = 4 * EPS16[prec]
+    assert torch.allclose(out[:M].float(), ref, rtol=tol, atol=2 * tol)
+    assert torch.all(out[M:] == 3.0)
+    o2 = torch.zeros(M, N, dtype=dt, device=d)
+    hip.gemm(A, W, bias, o2, epilogue=hip.EPI_H16, prec=prec, kernel=hip.KERNEL_256)
+    assert torch.equal(out[:M], o2)
+    for _ in range(3):      # the schedule has no data-dependent path: repeated runs are bit-identical
+        o3 = torch.zeros(M, N, dtype=dt, device=d)
+        hip.gemm(A, W, bias, o3, epilogue=hip.EPI_H16, prec=prec, kernel=hip.KERNEL_PP)
+        assert torch.equal(o3, o2)
+    with pytest.raises(hip.GavaError):       # K % 128 != 0
+        hip.gemm(A[:, :192].contiguous(), W[:, :192].contiguous(), None, o2, epilogue=hip.EPI_H16, prec=prec, kernel=hip.KERNEL_PP)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,D", [(45000, 768), (300, 768), (20000, 1024)])
+def test_ping_pong_loop_in_the_forward_forms_is_bit_identical(prec, M, D):
+    """The forms the inference driver launches on the ping-pong loop - residual producers with the 16-bit copy and the
+    pre-reduced row sums (out_proj: K = D, fc2: K = 4D), LayerNorm-folded consumers in partials and stats mode (qkv with the
+    scaled columns, fc1 with QuickGELU), the weight-lo pass (w_lo = 1) - against the default loop on the same inputs: every
+    output bit for bit (same k order, same epilogue code), ragged last tile, several tiles per workgroup."""
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    Mp = (M + 255) // 256 * 256
+    for K in (D, 4 * D):
+        A = rnd((M, K), 1.0, 1).to(d).to(dt)
+        W = rnd((D, K), K ** -0.5, 2).to(d).to(dt)
+        b = rnd((D,), 0.3, 3).to(d)
+        X0 = (rnd((M, D), 1.0, 4) + 0.5).to(d)
+        res = []
+        for kern in (hip.KERNEL_256, hip.KERNEL_PP):
+            X = X0.clone()
+            x16 = torch.zeros(Mp, D, dtype=dt, device=d)
+            part = torch.zeros(Mp + 32, 4, 2, dtype=torch.float32, device=d)
+            hip.gemm(A, W, b, X, epilogue=hip.EPI_F32, prec=prec, resid=X, x16_out=x16, rowsum_out=part, rowsum_reduced=True, kernel=kern)
+            Y = torch.zeros(M, D, device=d)
+            hip.gemm(A, W, b, Y, epilogue=hip.EPI_F32, prec=prec, resid=X0, kernel=kern)      # out of place, no producer extras
+            res.append((X, x16, part[:M, :D // 256].clone(), Y))
+        for a_, b_ in zip(*res):
+            assert torch.equal(a_, b_), K
+        assert torch.allclose(res[1][0], X0 + A.float() @ W.float().t() + b, rtol=1e-4, atol=1e-4)
+    X, x16, part_, _ = res[1]
+    part = torch.zeros(Mp + 32, 4, 2, dtype=torch.float32, device=d); part[:M, :D // 256] = part_
+    stats = torch.zeros(Mp, 2, device=d)
+    stats[:M, 0], stats[:M, 1] = X.mean(1), (X.var(1, unbiased=False) + 1e-5).rsqrt()
+    gamma = (1 + rnd((D,), 0.2, 5)).to(d)
+    for N, epi in ((3 * D, hip.EPI_H16), (4 * D, hip.EPI_H16_QGELU)):
+        Wf = (rnd((N, D), D ** -0.5, 7).to(d) * gamma).to(dt)
+        fs, ft = Wf.float().sum(1).contiguous(), rnd((N,), 0.3, 8).to(d)
+        kw = dict(scale_cols=N // 3, scale=0.125) if epi == hip.EPI_H16 else {}
+        for mode in (dict(fold_partials=part), dict(fold_stats=stats)):
+            outs = []
+            for kern in (hip.KERNEL_256, hip.KERNEL_PP):
+                o = torch.zeros(M, N, dtype=dt, device=d)
+                hip.gemm(x16[:M], Wf, None, o, epilogue=epi, prec=prec, fold_s=fs, fold_t=ft, kernel=kern, **mode, **kw)
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1]), (N, list(mode))
+        # weight-lo pass on the ping-pong loop
+        lo = (rnd((N, D), D ** -0.5, 7).to(d) * gamma - Wf.float()).to(dt)
+        Wp = torch.cat([Wf, lo], 1).contiguous()
+        outs = []
+        for kern in (hip.KERNEL_256, hip.KERNEL_PP):
+            o = torch.zeros(M, N, dtype=dt, device=d)
+            hip.gemm(x16[:M], Wp, None, o, epilogue=epi, prec=prec, fold_partials=part, fold_s=fs, fold_t=ft, w_lo=1, kernel=kern, **kw)
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1])
