@@ -863,7 +863,11 @@ void gemm256_kernel(const GemmParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           // ---- load section: the fragments of this phase's quadrant ...
+#ifdef GAVA_PP_NOREADS      // experiment builds (results WRONG): the loop without its fragment reads
+          if (kt < 0) {
+#else
           if (q == 0) {
+#endif
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
               w0f[jj][0] = *reinterpret_cast<const s16x8_t*>(buf + 1 * HALF + pp_w + jj * PP_WJ + pp_k0);
@@ -874,13 +878,21 @@ void gemm256_kernel(const GemmParams p) {
               af[i][0] = *reinterpret_cast<const s16x8_t*>(buf + 0 * HALF + pp_a + i * 2048 + pp_k0);
               af[i][1] = *reinterpret_cast<const s16x8_t*>(buf + 0 * HALF + pp_a + i * 2048 + pp_k1);
             }
+#ifdef GAVA_PP_NOREADS
+          } else if (kt < 0) {
+#else
           } else if (q == 1) {
+#endif
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
               w1f[jj][0] = *reinterpret_cast<const s16x8_t*>(buf + 2 * HALF + pp_w + jj * PP_WJ + pp_k0);
               w1f[jj][1] = *reinterpret_cast<const s16x8_t*>(buf + 2 * HALF + pp_w + jj * PP_WJ + pp_k1);
             }
+#ifdef GAVA_PP_NOREADS
+          } else if (kt < 0) {
+#else
           } else if (q == 2) {
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               af[i][0] = *reinterpret_cast<const s16x8_t*>(buf + 3 * HALF + pp_a + i * 2048 + pp_k0);
@@ -899,7 +911,9 @@ void gemm256_kernel(const GemmParams p) {
           }
           const int ktt = kt + (q < 2 ? 1 : 2);
           const bool more = ktt < nk || has_next;
+#ifndef GAVA_PP_NOGLDS      // experiment builds (results WRONG): the loop without its LDS-DMA
           if (more) stage_half(ktt < nk ? ktt : ktt - nk, (q + 2) & 3, q < 2 ? (B ^ 1) : B);
+#endif
           // ... and the wait that retires what the NEXT phase reads: half-tiles up to "this phase + 2"; the four younger ones
           // (8 pieces of this wave) stay in flight, plus the fold block's 3 loads while they are younger than the half-tile
           // waited for, plus - in the first k-tile after an epilogue - that epilogue's stores (counted: exactly NSTORE / 2 NSTORE per wave)
@@ -909,8 +923,8 @@ void gemm256_kernel(const GemmParams p) {
           else if (CAN_FOLD && kt == nk - 2 && has_next) wait_vm(11);
           else wait_vm(8);
           __builtin_amdgcn_s_barrier();
-          // every wave of BOTH groups has left the previous tile's epilogue (group 1 runs a barrier behind): its row-sum partials are complete
-          if (X16_STAGE && p.rowsum_reduced && kt == 0 && q == 1 && j > 0) flush_rowsum(m0p, n0p);
+          // every wave of both groups has left the previous tile's epilogue (they ran it side by side): its row-sum partials are complete
+          if (X16_STAGE && p.rowsum_reduced && kt == 0 && q == 0 && j > 0) flush_rowsum(m0p, n0p);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           // ---- MFMA section: quadrant (mi, ni) = (0,0) (0,1) (1,1) (1,0)
@@ -934,6 +948,10 @@ void gemm256_kernel(const GemmParams p) {
         pp_ktile(kt, std::integral_constant<int, 0>{});
         pp_ktile(kt + 1, std::integral_constant<int, 1>{});
       }
+      // The epilogues of the two groups must run side by side, not one after the other (a group that is a barrier ahead would
+      // wait at its next barrier for the other group's whole epilogue, and vice versa): group 0 waits here for group 1's last
+      // phase, both run the epilogue, and group 1 falls a barrier behind again at its end (below).
+      if (wr == 0) __builtin_amdgcn_s_barrier();
     } else
     for (int kt = 0; kt < nk; ++kt) {
       const int g = j * NT + kt;
@@ -1254,10 +1272,10 @@ void gemm256_kernel(const GemmParams p) {
     // those cases fall back to vmcnt(0)).
     counted = (full && !ACC_RES && !(ABLATE & 4) && !(EPI == GAVA_EPI_F32 && p.x16)) ? ((EPI == GAVA_EPI_H16_QGELU && p.aux_out) ? 2 : 1) : 0;
     if (L8 && p.out8 && counted) counted = counted == 1 ? 3 : 0;
+    if (PP && wr == 1 && j + 1 < my_tiles) __builtin_amdgcn_s_barrier();     // group 1 one barrier behind again
     m0p = m0; n0p = n0;
     m0 = m0n; n0 = n0n;
   }
-  if (PP && wr == 0) __builtin_amdgcn_s_barrier();     // pairs with group 1's last barrier
   if (X16_STAGE && p.rowsum_reduced) {
     __syncthreads();
     flush_rowsum(m0p, n0p);
@@ -1288,8 +1306,9 @@ int aligned_walk_sm(int tiles_m, int tiles_n, int sn, int blocks, int avail) {
   return rounds_aligned <= rounds_plain ? a_sm : 0;
 }
 
-// where AUTO takes the ping-pong loop: GAVA_PP = 0 nowhere, 1 wherever an instantiation exists, 2 (default) the residual
-// producers only (out_proj / fc2: measured faster there, K = 3072 by 4 %; the K = 768 consumers are 3-4 % slower on it)
+// where AUTO takes the ping-pong loop: GAVA_PP = 0 nowhere, 1 wherever an instantiation exists, 2 (default) the fp32-output
+// GEMMs - the residual producers out_proj / fc2 and the deep-K dgrad GEMMs of the backward (measured faster there: K = 3072 by
+// 4-7 %, out_proj by 3 %; the K = 768 LayerNorm-folded consumers are 3-4 % slower on it: profiles/r04_pingpong.txt)
 int pp_mode() {
   static const int v = getenv("GAVA_PP") ? atoi(getenv("GAVA_PP")) : 2;
   return v;
@@ -1366,7 +1385,7 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
   {
     const bool can_pp = gp.K % 128 == 0 && (gp.w_lo == 1 ? 2 : 1) * gp.K >= 256 && !gp.split_out && !gp.aux_out && !gp.aux;
     const bool want_pp = gp.kernel == GAVA_KERNEL_PP ||
-                         (gp.kernel == GAVA_KERNEL_AUTO && (pp_mode() == 1 || (pp_mode() == 2 && epi == GAVA_EPI_F32 && gp.resid)));
+                         (gp.kernel == GAVA_KERNEL_AUTO && (pp_mode() == 1 || (pp_mode() == 2 && epi == GAVA_EPI_F32 && (gp.resid || gp.K >= 2048))));
     if (gp.kernel == GAVA_KERNEL_PP && !can_pp) return GAVA_EINVAL;
     if (want_pp && can_pp) {
       bool done = true;
@@ -1380,6 +1399,10 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
         hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, true, false, false, true, 0, true>), grid, block, 0, s, gp);
       else if (epi == GAVA_EPI_F32 && gp.resid)
         hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, true, false, false, false, 0, true>), grid, block, 0, s, gp);
+      else if (epi == GAVA_EPI_F32 && align)          // the dgrad GEMMs of the backward (fp32 gradient accumulator, no residual)
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, false, false, false, true, 0, true>), grid, block, 0, s, gp);
+      else if (epi == GAVA_EPI_F32)
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, false, false, false, false, 0, true>), grid, block, 0, s, gp);
       else
         done = false;
       if (done) { GAVA_CHECK_LAUNCH(); return GAVA_OK; }
