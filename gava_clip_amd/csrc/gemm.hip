@@ -1306,6 +1306,13 @@ int aligned_walk_sm(int tiles_m, int tiles_n, int sn, int blocks, int avail) {
   return rounds_aligned <= rounds_plain ? a_sm : 0;
 }
 
+// round-4 A/B: the two-pass patch embedding's GEMM (A = the 16-bit patch matrix) on the persistent 256^2 kernel instead of the
+// 128^2 tile kernel; GAVA_PATCH_256=0 / 1
+bool patch_on_256() {
+  static const int v = getenv("GAVA_PATCH_256") ? atoi(getenv("GAVA_PATCH_256")) : 0;
+  return v != 0;
+}
+
 // where AUTO takes the ping-pong loop: GAVA_PP = 0 nowhere, 1 wherever an instantiation exists, 2 (default) the fp32-output
 // GEMMs - the residual producers out_proj / fc2 and the deep-K dgrad GEMMs of the backward (measured faster there: K = 3072 by
 // 4-7 %, out_proj by 3 %; the K = 768 LayerNorm-folded consumers are 3-4 % slower on it: profiles/r04_pingpong.txt)
@@ -1785,7 +1792,8 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   // ... and, since the fp32-output kernels use the natural column order (64 contiguous bytes per row and instruction in
   // the residual loads and the stores), also for the shallow fp32 GEMM: out 0.251 vs 0.268 ms on the 128^2 kernel
   if (gp.N % 256 == 0 && fits32 &&
-      (gp.N >= 1536 || (gp.K >= 2048 && tiles256 >= 512) || (epi == GAVA_EPI_F32 && tiles256 >= 512) || variant == 3))
+      (gp.N >= 1536 || (gp.K >= 2048 && tiles256 >= 512) || (epi == GAVA_EPI_F32 && tiles256 >= 512) || variant == 3 ||
+       (epi == GAVA_EPI_F32_PATCH && tiles256 >= 512 && patch_on_256())))
     return launch_256<P, 3>(gp, epi, s);
   return launch_tile<P, 128, 128, 2>(gp, epi, s);
 }

@@ -18,7 +18,7 @@ python - <<PY
 import json
 for c in ("c2", "c3", "c5", "c2_2rank_gloo"):
     try:
-        d = json.load(open("$O/bench_%s.json" % c))
+        d = json.loads([l for l in open("$O/bench_%s.json" % c).read().splitlines() if l.strip()][-1])
         r = d.get("roofline") or {}
         print(c, d["value"], d["ms_per_step"], r.get("frac"), r.get("traffic"), d.get("parity_modes"), (d.get("train_step") or {}).get("ms_per_step"), d["config"].get("parallelism"))
     except Exception as e:
