@@ -546,3 +546,43 @@ def test_split_precision_last_block_is_an_exact_option(golden_dir):
     assert bool(m._pack()["vis_layers"][TINY.num_layers - 1].w_q_split)
     assert not np.array_equal(a, b)
     assert rel_to_max(a, g["logits"]) < 1e-3 and rel_to_max(b, g["logits"]) < 1e-3 and rel_to_max(a, b) < 1e-3
+
+
+@pytest.mark.parametrize("mode", WLO_MODES)
+def test_weight_lo_modes_on_small_shapes_the_uint8_path_and_training(golden_dir, mode):
+    """The weight-lo modes away from the big persistent GEMMs: the TINY config (D = 64: every GEMM on the 128^2 tile kernel, the
+    8-bit mode degrades to the 16-bit lo product there) against the reference's per-layer fixtures; forward_frames (decoded uint8
+    videos: two-pass patch matrix + GEMM with the lo pass) == forward of the preprocessed batch bit for bit; and loss.backward()
+    on a model in a weight-lo mode: training always uses the plain packing, so its gradients are an fp16 model's (up to the atomics' summation order in LayerNorm')."""
+    from gava_clip_amd.preprocess import ClipPreprocessor
+    g = np.load(os.path.join(golden_dir, "tiny.npz"))
+    m, sd = build(TINY, mode)
+    x = torch.from_numpy(synth.synth_clip(2, TINY.num_frames, TINY.input_size)).cuda()
+    with torch.no_grad():
+        lg = m(x)[0]
+    cls = m.last["cls_rows"].cpu().numpy()
+    for i in range(TINY.num_layers):
+        assert rel_to_max(cls[i], g[f"block{i}"][:, 0]) < 1e-3, f"cls rows after block {i}"
+    assert rel_to_max(lg.cpu().numpy(), g["logits"]) < 5e-4
+    m0, _ = build(TINY, "fp16")
+    with torch.no_grad():
+        e0 = rel_to_max(m0(x)[0].cpu().numpy(), g["logits"])
+    print(f"\n[tiny/{mode}] logits rel-to-max {rel_to_max(lg.cpu().numpy(), g['logits']):.2e} (fp16: {e0:.2e})")
+    # decoded uint8 videos
+    gen = torch.Generator().manual_seed(5)
+    vids = [torch.randint(0, 256, (9, 70, 90, 3), dtype=torch.uint8, generator=gen).cuda(), torch.randint(0, 256, (7, 64, 64, 3), dtype=torch.uint8, generator=gen).cuda()]
+    pre = ClipPreprocessor(num_frames=TINY.num_frames, sampling_rate=1, spatial_size=TINY.input_size, mean=(0.45, 0.45, 0.45), std=(0.225, 0.225, 0.225))
+    with torch.no_grad():
+        a, b = m.forward_frames(vids, pre)[0], m(pre.batch(vids))[0]
+    assert torch.equal(a, b)
+    # training on a model in a weight-lo mode == training on an fp16 model
+    grads = []
+    for mm in (m, m0):
+        mm.train()
+        mm.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(mm(x)[0], torch.tensor([0, 2], device="cuda")).backward()
+        grads.append({n: p.grad.clone() for n, p in mm.named_parameters() if p.grad is not None})
+        mm.eval()
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 5
+    for n in grads[0]:      # (LayerNorm' accumulates d gamma / d beta with atomics: equal up to the summation order)
+        assert torch.allclose(grads[0][n], grads[1][n], rtol=1e-4, atol=1e-7), n
