@@ -70,7 +70,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)     # SURVEY 8d protocol: >= 10 warm-up + >= 50 timed forwards
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--prec", default=os.environ.get("GAVA_PREC", "fp16"), choices=["fp16", "bf16"])
+    ap.add_argument("--prec", default=os.environ.get("GAVA_PREC", "fp16"), choices=["fp16", "bf16", "fp16+wlo", "fp16+wlo8"],
+                    help="MFMA operand mode of the timed forward; the +wlo modes are the parity modes (weight-lo pass, DESIGN 'Numerics')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the stand-alone kernel timings")
     ap.add_argument("--no-alt", action="store_true", help="skip the short run in the other operand dtype")
@@ -279,7 +280,7 @@ def accuracy_vs_golden(prec, include_c5=False):
     # default: the twelve c1 seeds, the full c2 batch, clip 0 of c3; --accuracy-c5 adds the full c3 batch and the ViT-L/14 fixtures
     names = [n for n in GOLDEN_LOGIT_CASES if include_c5 or not (n.startswith("c5") or n == "c3_full")]
     # ... and the two weight-lo parity modes of round 4 (DESIGN "Numerics": the configurations that meet 1e-3 on every fixture)
-    order = (prec, "bf16" if prec == "fp16" else "fp16", "fp16+wlo8", "fp16+wlo")
+    order = tuple(dict.fromkeys((prec, "bf16" if prec == "fp16" else "fp16", "fp16+wlo8", "fp16+wlo")))
     res = {"reference": "tests/golden/{%s}.npz (reference fp32 CPU forwards, tools/gen_golden.py)" % ",".join(names),
            "criteria": f"norm-wise max|d| <= 1e-3 max|ref|; element-wise |d| <= {LOGITS_RTOL} |ref| + {LOGITS_ATOL} (frozen, tests/helpers.py)"}
     per = {p_: {} for p_ in order}

@@ -818,3 +818,35 @@ def test_ping_pong_loop_in_the_forward_forms_is_bit_identical(prec, M, D):
             hip.gemm(x16[:M], Wp, None, o, epilogue=epi, prec=prec, fold_partials=part, fold_s=fs, fold_t=ft, w_lo=1, kernel=kern, **kw)
             outs.append(o)
         assert torch.equal(outs[0], outs[1])
+
+
+def test_ping_pong_loop_race_screen_under_load():
+    """A new synchronisation structure is screened, not trusted after one clean run (cdna_hip_programming.md: an early read of a
+    staged buffer passes whenever the DMA happens to land first): 40 rounds over several row counts and depths - ragged and
+    full tiles, one and many tiles per workgroup, K = 256 (the shortest pipeline: prologue and tile switch back to back) to
+    3072 - while a second stream streams 256 MB through HBM to perturb every latency; every output compared bit for bit with
+    the default loop's."""
+    d = dev()
+    prec, dt = hip.PREC_F16, torch.float16
+    shapes = [(70000, 768, 768), (45000, 768, 3072), (257, 256, 256), (66000, 512, 256), (30000, 1024, 1024)]
+    noise_a = torch.empty(64 * 2 ** 20, device=d)
+    noise_b = torch.empty_like(noise_a)
+    side = torch.cuda.Stream()
+    cases = []
+    for (M, N, K) in shapes:
+        A = rnd((M, K), 1.0, M % 97).to(d).to(dt)
+        W = rnd((N, K), K ** -0.5, 2).to(d).to(dt)
+        X0 = rnd((M, N), 1.0, 4).to(d)
+        ref = X0.clone()
+        hip.gemm(A, W, None, ref, epilogue=hip.EPI_F32, prec=prec, resid=ref, kernel=hip.KERNEL_256)
+        cases.append((A, W, X0, ref))
+    torch.cuda.synchronize()
+    for it in range(40):
+        with torch.cuda.stream(side):
+            noise_b.copy_(noise_a)
+            noise_a.copy_(noise_b)
+        A, W, X0, ref = cases[it % len(cases)]
+        X = X0.clone()
+        hip.gemm(A, W, None, X, epilogue=hip.EPI_F32, prec=prec, resid=X, kernel=hip.KERNEL_PP)
+        assert torch.equal(X, ref), (it, tuple(A.shape))
+    torch.cuda.synchronize()
