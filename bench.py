@@ -277,7 +277,7 @@ def accuracy_vs_golden(prec, include_c5=False):
     from gava_clip_amd import VitaCLIP, synth
     from helpers import (GOLDEN_LOGIT_CASES, golden_case, model_kwargs, synth_torch_state, mixed_violation,
                          LOGITS_RTOL, LOGITS_ATOL)
-    # default: the twelve c1 seeds, the full c2 batch, clip 0 of c3; --accuracy-c5 adds the full c3 batch and the ViT-L/14 fixtures
+    # default: the twenty-four c1 seeds, the full c2 batch, clip 0 of c3; --accuracy-c5 adds the full c3 batch and the ViT-L/14 fixtures
     names = [n for n in GOLDEN_LOGIT_CASES if include_c5 or not (n.startswith("c5") or n == "c3_full")]
     # ... and the two weight-lo parity modes of round 4 (DESIGN "Numerics": the configurations that meet 1e-3 on every fixture)
     order = tuple(dict.fromkeys((prec, "bf16" if prec == "fp16" else "fp16", "fp16+wlo8", "fp16+wlo")))

@@ -57,6 +57,7 @@ GOLDEN_LOGIT_CASES = {
     "c1_b16_s2": ("VIT_B16_T8", "3", 2, 2, 1236),
     "c1_b16_s3": ("VIT_B16_T8", "3", 2, 3, 1237),
     **{f"c1_b16_s{i}": ("VIT_B16_T8", "3", 2, i, 1234 + i) for i in range(4, 12)},     # tools/gen_golden.py --more-seeds
+    **{f"c1_b16_s{i}": ("VIT_B16_T8", "3", 2, i, 1234 + i) for i in range(12, 24)},    # tools/gen_golden.py --round4
     "c2_full": ("VIT_B16_T8", "3", 64, 0, 4242),                                        # tools/gen_golden.py --c2-full
     "c3_clip0": ("VIT_B16_T16", "400", 1, 0, 3),
     "c5_clip0": ("VIT_L14_T32", "3", 1, 0, 5),
@@ -71,7 +72,13 @@ GOLDEN_LOGIT_CASES = {
 # NORM-WISE bar max|d| <= 1e-3 max|ref| is met by ten of the twelve seeds (median 5.7e-4) and missed by these two (1.25e-3,
 # 1.51e-3).  The frozen mixed criterion holds on all of them (worst 0.93 of its bound).  The tests assert the norm-wise bar on
 # every seed and mark these two as expected failures (strict: an improvement of the numerics shows up as XPASS).
-NORMWISE_KNOWN_MISSES = ("c1_b16_s5", "c1_b16_s6")
+NORMWISE_KNOWN_MISSES = ("c1_b16_s5", "c1_b16_s6", "c1_b16_s13")
+# Round 4: twelve more c1 seeds (s12 ... s23, tools/gen_golden.py --round4) were added to judge the weight-lo parity modes on 24
+# seeds.  In the DEFAULT fp16 mode one of them misses the norm-wise bar (s13: 1.03e-3) and two miss the frozen mixed criterion
+# itself (s13: 1.10, s18: 1.30 of the bound) - the constants stay frozen, the misses are listed here and asserted as strict
+# expected failures (3 of 24 seeds norm-wise, 2 of 24 mixed).  The cause is the fp16 rounding of the weights (DESIGN "Numerics");
+# operand_dtype "fp16+wlo" / "fp16+wlo8" meet both criteria on all 24 seeds (worst norm-wise 4.6e-4, worst mixed 0.38).
+MIXED_KNOWN_MISSES = ("c1_b16_s13", "c1_b16_s18")
 
 
 def golden_case(name):

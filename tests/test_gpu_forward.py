@@ -84,35 +84,64 @@ def test_c1_vit_b16_vs_golden(golden_dir, prec, tol):
     assert tuple(m.text_features.shape) == (3, 512)
 
 
+_C1_MODEL, _C1_RESULTS = {}, {}
+_C1_MODES = ("fp16", "fp16+wlo", "fp16+wlo8")
+
+
+class _Last:
+    def __init__(self, vf, tf):
+        self.last, self.text_features = {"video_features": vf}, tf
+
+
 def _c1_seed_logits(golden_dir, name, prec="fp16"):
+    """Logits (+ features) of one c1 reference fixture in one operand mode.  One ViT-B/16 model stays on the device for all the
+    seed tests and the first test that touches a seed runs it in every mode (synthesising 185 M weights is what a seed costs):
+    the four tests of a seed share the results."""
     from helpers import golden_case
     cfg, class_file, n_cls, B, wseed, xseed = golden_case(name)
     g = np.load(os.path.join(golden_dir, name + ".npz"))
-    m = VitaCLIP(**model_kwargs(cfg, class_file), operand_dtype=prec)
-    m.load_state_dict(synth_torch_state(cfg, n_cls, wseed), strict=True)
-    m = m.cuda().eval()
-    x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size, seed=xseed)).cuda()
-    with torch.no_grad():
-        lg = m(x)[0].cpu().numpy()
-    return lg, g, m
+    if name not in _C1_RESULTS:
+        m = _C1_MODEL.get("m")
+        if m is None:
+            m = _C1_MODEL["m"] = VitaCLIP(**model_kwargs(cfg, class_file), operand_dtype="fp16").cuda().eval()
+        m.load_state_dict({k: v.cuda() for k, v in synth_torch_state(cfg, n_cls, wseed).items()}, strict=True)
+        x = torch.from_numpy(synth.synth_clip(B, cfg.num_frames, cfg.input_size, seed=xseed)).cuda()
+        res = {}
+        for mode in _C1_MODES:
+            m.set_operand_dtype(mode)
+            with torch.no_grad():
+                lg = m(x)[0].cpu().numpy()
+            res[mode] = (lg, m.last["video_features"].clone(), m.text_features.clone())
+        m.set_operand_dtype("fp16")
+        _C1_RESULTS[name] = res
+    lg, vf, tf = _C1_RESULTS[name][prec]
+    return lg, g, _Last(vf, tf)
 
 
-C1_SEEDS = ["c1_b16_s%d" % i for i in range(1, 12)]
+C1_SEEDS = ["c1_b16_s%d" % i for i in range(1, 24)]
 
 
-@pytest.mark.parametrize("name", C1_SEEDS)
+def _mixed_params():
+    from helpers import MIXED_KNOWN_MISSES
+    return [pytest.param(n, marks=pytest.mark.xfail(strict=True, reason="known deviation of the default fp16 mode (tests/helpers.py "
+                                                    "MIXED_KNOWN_MISSES); the weight-lo modes pass it")) if n in MIXED_KNOWN_MISSES else n
+            for n in C1_SEEDS]
+
+
+@pytest.mark.parametrize("name", _mixed_params())
 def test_c1_other_seeds_meet_the_frozen_mixed_criterion(golden_dir, name):
-    """Eleven more reference runs at c1 shapes (other weights AND other clips; tools/gen_golden.py --round3 / --more-seeds),
-    judged by the frozen element-wise criterion of tests/helpers.py (|d| <= 1e-3 |ref| + 5e-4): holds on every seed."""
+    """Twenty-three more reference runs at c1 shapes (other weights AND other clips; tools/gen_golden.py --round3 / --more-seeds /
+    --round4), judged by the frozen element-wise criterion of tests/helpers.py (|d| <= 1e-3 |ref| + 5e-4) in the DEFAULT fp16
+    mode: holds on 21 of them; the two of round 4's twelve new seeds that miss it are strict expected failures (helpers.py)."""
     lg, g, m = _c1_seed_logits(golden_dir, name)
     e_rel, viol = rel_to_max(lg, g["logits"]), mixed_violation(lg, g["logits"])
     print(f"\n[{name}] max|ref| {np.abs(g['logits']).max():.3f} rel-to-max {e_rel:.3e} mixed {viol:.3f}; "
           f"video {rel_to_max(m.last['video_features'].cpu().numpy(), g['video_features']):.3e} "
           f"text {rel_to_max(m.text_features.cpu().numpy(), g['text_features']):.3e}")
-    assert viol <= 1.0
     assert rel_to_max(m.text_features.cpu().numpy(), g["text_features"]) < 2e-5      # fp32 softmax core + split-precision GEMMs
     assert rel_to_max(m.last["video_features"].cpu().numpy(), g["video_features"]) < 1e-3
     assert np.array_equal(lg.argmax(-1), g["logits"].argmax(-1))
+    assert viol <= 1.0
 
 
 def _normwise_params():
@@ -124,8 +153,8 @@ def _normwise_params():
 
 @pytest.mark.parametrize("name", _normwise_params())
 def test_c1_other_seeds_normwise_bar(golden_dir, name):
-    """north_star's bar read norm-wise (max|d| <= 1e-3 max|ref|) on the same eleven seeds: met by nine, missed by two whose
-    logits are all small - recorded as expected failures, not hidden (DESIGN.md "Numerics", tools/accuracy_sweep.py)."""
+    """north_star's bar read norm-wise (max|d| <= 1e-3 max|ref|) on the same twenty-three seeds in the DEFAULT fp16 mode: met by
+    twenty, missed by three - recorded as expected failures, not hidden (DESIGN.md "Numerics", tools/wlo_modes.py)."""
     lg, g, _ = _c1_seed_logits(golden_dir, name)
     assert rel_to_max(lg, g["logits"]) < 1e-3
 
@@ -137,8 +166,8 @@ WLO_MODES = ["fp16+wlo", "fp16+wlo8"]
 @pytest.mark.parametrize("name", ["c1_b16"] + C1_SEEDS)
 def test_weight_lo_modes_meet_the_normwise_bar_on_every_c1_seed(golden_dir, name, mode):
     """The parity modes of round 4 (operand_dtype "fp16+wlo": every vision GEMM also multiplies by W - h16(W)):
-    north_star's bar read norm-wise, max|d| <= 1e-3 max|ref|, on ALL twelve c1 reference fixtures with NO expected failure -
-    including s5 / s6, which the plain fp16 path misses (helpers.NORMWISE_KNOWN_MISSES)."""
+    north_star's bar read norm-wise, max|d| <= 1e-3 max|ref|, AND the frozen mixed criterion on ALL twenty-four c1 reference
+    fixtures with NO expected failure - including s5 / s6 / s13 / s18, which the plain fp16 path misses (helpers.*_KNOWN_MISSES)."""
     lg, g, m = _c1_seed_logits(golden_dir, name, mode)
     e_rel, viol = rel_to_max(lg, g["logits"]), mixed_violation(lg, g["logits"])
     vf = rel_to_max(m.last["video_features"].cpu().numpy(), g["video_features"])
@@ -152,7 +181,7 @@ def test_weight_lo_modes_meet_the_normwise_bar_on_every_c1_seed(golden_dir, name
 @pytest.mark.parametrize("name", ["c2_full", "c3_clip0", "c3_full", "c5_clip0", "c5_full"])
 def test_weight_lo_modes_on_the_full_size_fixtures(golden_dir, name):
     """The other five reference fixtures (full c2 / c3 / c5 batches, clip 0 of c3 and c5) in both weight-lo modes: with the
-    twelve c1 seeds above that is all 17 logit fixtures at norm-wise <= 1e-3 with no expected failure.  One model and one
+    twenty-four c1 seeds above that is all 29 logit fixtures at norm-wise <= 1e-3 with no expected failure.  One model and one
     input per fixture, the modes switched on it (set_operand_dtype re-packs the weights)."""
     from helpers import golden_case
     path = os.path.join(golden_dir, name + ".npz")

@@ -408,6 +408,10 @@ if __name__ == "__main__":
     if "--c2-full" in sys.argv:      # BASELINE config c2 at its full batch: 64 clips through the reference (logits + features only)
         run_case(mod, VIT_B16_T8, C3, 64, "c2_full", False, wseed=0, xseed=4242, compact=True)
         sys.exit(0)
+    if "--round4" in sys.argv:       # twelve more weight + input seeds at c1 (round 4: the weight-lo parity modes are judged on 24 c1 seeds)
+        for sidx in range(12, 24):
+            run_case(mod, VIT_B16_T8, C3, 2, f"c1_b16_s{sidx}", False, wseed=sidx, xseed=1234 + sidx, compact=True)
+        sys.exit(0)
     if "--more-seeds" in sys.argv:   # further weight + input seeds at c1 (statistics of the logits error; compact fixtures)
         for sidx in range(4, 12):
             run_case(mod, VIT_B16_T8, C3, 2, f"c1_b16_s{sidx}", False, wseed=sidx, xseed=1234 + sidx, compact=True)
