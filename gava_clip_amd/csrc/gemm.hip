@@ -1779,6 +1779,13 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   // the im2col-free patch loader lives in the templated kernel
   // im2col-free patch embedding: 128 x 256 tiles (8 waves) build every A tile for 3 instead of 6 N-tiles at D = 768
   if ((gp.frames || gp.clips) && gp.N % 256 == 0 && variant != 1 && variant != 10) return launch_tile<P, 128, 256, 2>(gp, epi, s);
+  // small-M problems are a latency chain (the prompt path: 8 dependent launches of <= 36 workgroups each, beside the streaming QKV GEMM):
+  // a 4-deep operand ring (three k-tiles in flight; 128 KiB of LDS, one workgroup per CU - they have few) hides the latencies they see
+  // there.  Round 4, same box: stand-alone they take 11-12 us each whatever the depth, the c2 forward 21.31 -> 21.15 ms
+  // (profiles/r04_pingpong.txt).  GAVA_SMALL_NST=2|3|4: A/B.
+  static const int small_nst = getenv("GAVA_SMALL_NST") ? atoi(getenv("GAVA_SMALL_NST")) : 4;
+  if (!gp.frames && !gp.clips && gp.M <= 2048 && variant != 1 && variant != 10 && small_nst == 4) return launch_tile<P, 128, 128, 4>(gp, epi, s);
+  if (!gp.frames && !gp.clips && gp.M <= 2048 && variant != 1 && variant != 10 && small_nst == 3) return launch_tile<P, 128, 128, 3>(gp, epi, s);
   if (gp.frames || gp.clips || gp.M <= 2048 || variant == 1 || variant == 10) return launch_tile<P, 128, 128, 2>(gp, epi, s);
   if (variant == 2) return launch_tile<P, 256, 128, 3>(gp, epi, s);
   if (variant == 12 && gp.N % 256 == 0) return launch_tile<P, 128, 256, 2>(gp, epi, s);
