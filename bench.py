@@ -145,14 +145,14 @@ def train_roofline(cfg, B):
     avg_ms = sum(r["ms_per_launch"] * r["launches_per_step"] for r in rows) / n
     avg_fl = sum(r["flops_per_launch"] * r["launches_per_step"] for r in rows) / n
     walk = "true" if hip.load().gava_gemm_aligned_walk(R, D, 0) else "false"
-    return {"bound": "mfma", "kernel": f"gemm256_kernel<PrecBF16, 2, false, false, false, {walk}, 0> = the dgrad GEMMs with the fp32 gradient-accumulator epilogue",
+    return {"bound": "mfma", "kernel": f"gemm256_kernel<PrecBF16, 2, false, false, false, {walk}, 0, true, false> = the dgrad GEMMs with the fp32 gradient-accumulator epilogue",
             "achieved": round(avg_fl / avg_ms / 1e9, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(avg_fl / avg_ms / 1e9 / PEAK_MFMA_TFLOPS, 4),
             "ms_per_launch": round(avg_ms, 4), "launches_per_step": n, "members": rows,
             "timed": "HIP events around 20 back-to-back launches after 10 warm-up launches, median of 3",
             "first_thing_to_fix": "see DESIGN.md section 7 (round 4): the step's largest non-GEMM shares"}
 
 
-def kernel_table(cfg, B, prec, fold=False):
+def kernel_table(cfg, B, prec, fold=False, pair=False):
     """Stand-alone timings of the per-layer kernels at this config's shapes (through the C ABI)."""
     from gava_clip_amd import hip
     dt = hip.h16_dtype(prec)
@@ -228,19 +228,34 @@ def kernel_table(cfg, B, prec, fold=False):
                                                                       rowsum_reduced=True),
                 2.0 * R * D * F, R * F * 2 + R * D * 10 + D * F * 2 + R * (D // 64) * 8)}
     X16 = torch.empty(R, D, dtype=dt, device=d)
+    if fold and pair:
+        # ... and when the driver keeps the residual stream as a 16-bit pair (gava_vision_pair_stream: big batches): the producers read
+        # and write hi / lo (8 bytes per element through the epilogue: pair in, pair out - the hi half IS the 16-bit copy)
+        X16 = X.to(dt)
+        XLO = (X - X16.float()).half()
+        folded["out"] = ("gemm out  +res pair -> pair +row sums", lambda: hip.gemm(MIX, Wo, bo, None, epilogue=hip.EPI_F32, prec=prec, resid16=X16, resid_lo=XLO,
+                                                                                 x16_out=X16, xlo_out=XLO, rowsum_out=part, rowsum_reduced=True),
+                         2.0 * R * D * D, R * D * 2 + R * D * 8 + D * D * 2 + R * (D // 64) * 8)
+        folded["fc2"] = ("gemm fc2  +res pair -> pair +row sums", lambda: hip.gemm(HID, W2, b2, None, epilogue=hip.EPI_F32, prec=prec, resid16=X16, resid_lo=XLO,
+                                                                                 x16_out=X16, xlo_out=XLO, rowsum_out=part, rowsum_reduced=True),
+                         2.0 * R * D * F, R * F * 2 + R * D * 8 + D * F * 2 + R * (D // 64) * 8)
     first, second = (folded, plain) if fold else (plain, None)
     # which instantiation each shape runs as (the name rocprofv3 prints; out_proj and fc2 share one), and how often the
     # inference forward launches it: with the fold, block 0's qkv and the last block run other kernels (forward.hip)
     Lyr = cfg.num_layers
     PN = "PrecF16" if prec == hip.PREC_F16 else "PrecBF16"
-    # template arguments: precision, epilogue, residual, split output, LayerNorm fold, aligned tile walk, 8-bit lo mode;
+    # template arguments: precision, epilogue, residual, split output, LayerNorm fold, aligned tile walk, 8-bit lo mode, ping-pong
+    # k-loop, residual stream as a 16-bit pair;
     # the walk is the launcher's own decision for this shape on this device (gava_gemm_aligned_walk), not assumed
     walk = "true" if hip.load().gava_gemm_aligned_walk(R, D, 0) else "false"
     pp_env = os.environ.get("GAVA_PP", "2")      # the launcher's switch: 2 (default) = ping-pong k-loop for the fp32-output GEMMs
     pp, ppc = ("true" if pp_env in ("1", "2") else "false"), ("true" if pp_env == "1" else "false")
-    inst = {"qkv": f"gemm256_kernel<{PN}, 0, false, false, {'true' if fold else 'false'}, false, 0, {ppc}>",
-            "fc1": f"gemm256_kernel<{PN}, 1, false, false, {'true' if fold else 'false'}, false, 0, {ppc}>",
-            "out": f"gemm256_kernel<{PN}, 2, true, false, false, {walk}, 0, {pp}>", "fc2": f"gemm256_kernel<{PN}, 2, true, false, false, {walk}, 0, {pp}>"}
+    hl = "true" if (fold and pair) else "false"
+    if fold and pair:
+        pp = "true"          # the pair instantiations exist on the ping-pong loop only
+    inst = {"qkv": f"gemm256_kernel<{PN}, 0, false, false, {'true' if fold else 'false'}, false, 0, {ppc}, false>",
+            "fc1": f"gemm256_kernel<{PN}, 1, false, false, {'true' if fold else 'false'}, false, 0, {ppc}, false>",
+            "out": f"gemm256_kernel<{PN}, 2, true, false, false, {walk}, 0, {pp}, {hl}>", "fc2": f"gemm256_kernel<{PN}, 2, true, false, false, {walk}, 0, {pp}, {hl}>"}
     calls = {"qkv": Lyr - 2 if fold else Lyr - 1, "fc1": Lyr - 1, "out": Lyr - 1, "fc2": Lyr - 1}
     # per-layer order of the forward; the kernels the forward launches come first, at the positions they always had
     add("layernorm f32->h16 [R,D]", lambda: hip.layernorm(X, gam, bet, out16=Xn, prec=prec), 0, R * D * 6, "layernorm_kernel", 0, None)
@@ -455,7 +470,7 @@ def main():
     if solo and not a.no_kernels:
         log("stand-alone kernel timings")
         fold = bool(getattr(model, "fold_layernorm", False))
-        rows = kernel_table(cfg, B, model.prec, fold=fold)
+        rows = kernel_table(cfg, B, model.prec, fold=fold, pair=bool(model.last.get("pair_stream")))
         out["kernels"] = [{k: r[k] for k in ("kernel", "ms", "tflops", "gbps")} for r in rows]
         # ---- roofline: the kernel INSTANTIATION with the largest share of the forward's GPU time (what the first row of a
         # rocprofv3 --kernel-trace --stats summary of this command shows; out_proj and fc2 of the vision blocks are one

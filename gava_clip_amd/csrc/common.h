@@ -75,6 +75,16 @@ static __device__ __forceinline__ void split4(float a, float b, float c, float d
                 c - P::up((unsigned short)hi.y), d - P::up((unsigned short)(hi.y >> 16)));
 }
 
+// the residual stream's pair: hi in the operand type, lo = fp16 of the remainder whatever the operand type (2^-22 of |x| with
+// fp16 operands, 2^-20 with bf16 ones)
+template <class P>
+static __device__ __forceinline__ void split4_lo16(float a, float b, float c, float d, uint2& hi, uint2& lo) {
+  hi.x = P::cvt2(a, b);
+  hi.y = P::cvt2(c, d);
+  lo = pack4<PrecF16>(a - P::up((unsigned short)hi.x), b - P::up((unsigned short)(hi.x >> 16)),
+                      c - P::up((unsigned short)hi.y), d - P::up((unsigned short)(hi.y >> 16)));
+}
+
 // x[l] + x[l ^ 16] + x[l ^ 32] + x[l ^ 48] in every lane, on the VALU: gfx950's v_permlane16_swap / v_permlane32_swap
 // instead of two dependent ds_bpermute round trips through the LDS pipe
 static __device__ __forceinline__ float sum_across_lane_groups(float x) {

@@ -92,9 +92,10 @@ struct Carver {
 
 int ln(const float* in, long in_stride, const int32_t* idx, const float* g, const float* b, void* o16, long o16s,
        float* o32, long o32s, int rows, int D, int prec, gava_stream_t s, int split = 0, const float* g2 = nullptr,
-       const float* b2 = nullptr) {
+       const float* b2 = nullptr, void* ohi = nullptr, void* olo = nullptr, long ohls = 0) {
   gava_layernorm_args a{};
   a.gamma2 = g2; a.beta2 = b2;
+  a.out_hi = ohi; a.out_lo = olo; a.out_hl_stride = ohls;
   a.in = in; a.in_stride = in_stride; a.in_row_index = idx; a.gamma = g; a.beta = b;
   a.out16 = o16; a.out16_stride = o16s; a.out32 = o32; a.out32_stride = o32s;
   a.rows = rows; a.D = D; a.prec = prec; a.split_out = split;
@@ -106,6 +107,8 @@ struct Fold {
   void* x16 = nullptr; long ld_x16 = 0; float* rowsum = nullptr; int reduced = 0;         // producer
   const float* stats = nullptr; const float* s = nullptr; const float* t = nullptr;       // consumer
   const float* partials = nullptr;                                                        // consumer, no row_stats launch
+  // producer with the residual stream as a 16-bit pair (gava_gemm_args.resid16): pair in (pitch = the call's ldr), lo out beside x16
+  const void* r16 = nullptr; const void* rlo = nullptr; void* xlo = nullptr;
 };
 
 // the 8-bit side of a GEMM in the w_lo = 2 mode (gava_gemm_args): its own lo product (W8 != NULL) and / or the bf8 copies it
@@ -133,6 +136,7 @@ int gemm_x(int w_lo, const void* A, long lda, const void* W, long ldw, const flo
   if (fold) {
     a.x16_out = fold->x16; a.ld_x16 = fold->ld_x16; a.rowsum_out = fold->rowsum; a.rowsum_reduced = fold->reduced;
     a.fold_stats = fold->stats; a.fold_s = fold->s; a.fold_t = fold->t; a.fold_partials = fold->partials;
+    a.resid16 = fold->r16; a.resid_lo = fold->rlo; a.xlo_out = fold->xlo;
   }
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo;
   a.resid = resid; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.prec = prec;
@@ -147,6 +151,7 @@ int gemm(const void* A, long lda, const void* W, long ldw, const float* bias, vo
 
 struct VisionWs {
   float* X; void* Xn; void* QKV; void* MIX; void* HID;
+  void* Xlo;                                     // the lo half of the residual stream's 16-bit pair (hi = Xn), see `pair` in the driver
   void* CLS16; float* CP; void* CPn; void* SQKV; void* SMIX; float* SUMM; void* SIDEn; void* SIDEKV;
   void* CLSPOST; float* PROJ;
   void* XNC; void* QC; void* MIXC; void* HIDC;   // last block: CLS rows only
@@ -193,6 +198,7 @@ VisionWs carve_vision(const gava_vision_model* m, void* ws, size_t cap) {
   VisionWs w;
   w.X = (float*)c.take(R * D * 4);
   w.Xn = c.take(R * D * 2);
+  w.Xlo = c.take(R * D * 2);
   w.QKV = c.take(R * 3 * D * 2);
   w.MIX = c.take(R * D * 2);
   {  // the fc1 output; before the blocks it parks the 16-bit patch matrix (patch_operand)
@@ -235,7 +241,23 @@ int check_vision(const gava_vision_model* m) {
   return GAVA_OK;
 }
 
+// does the inference driver keep the residual stream as a 16-bit pair for this model and batch? (see `pair` in the driver)
+bool pair_stream(const gava_vision_model* m) {
+  const long g = m->size / m->P, R = (long)m->B * m->T_in * (g * g + 1);
+  const int D = m->D, F = m->F, WL = m->w_lo ? 2 : 1;
+  bool pair = m->w_lo != 2 && m->layers >= 2 && R >= 8192 && D % 256 == 0 && D >= 256 &&
+              !(getenv("GAVA_FUSED_STATS") && getenv("GAVA_FUSED_STATS")[0] == '0') && !getenv("GAVA_NO_PREFUSE") && !getenv("GAVA_NO_LASTFOLD") &&
+              gava::gemm_takes_pair((int)R, D, D, D, (long)WL * D) && gava::gemm_takes_pair((int)R, D, F, F, (long)WL * F);
+  for (int i = 0; pair && i + 1 < m->layers; ++i) pair = m->layer[i].w_fc1_fold && m->layer[i + 1].w_qkv_fold;
+  return pair;
+}
+
 }  // namespace
+
+extern "C" int gava_vision_pair_stream(const gava_vision_model* m) {
+  if (check_vision(m) != GAVA_OK) return 0;
+  return pair_stream(m) ? 1 : 0;
+}
 
 // The ABI version is a hash of include/gava_hip.h, baked in by gava_clip_amd/build.py (-DGAVA_ABI_HASH): a library built from
 // another header than the one its caller mirrors is refused at load time (gava_clip_amd/hip.py load()).
@@ -323,7 +345,14 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
   constexpr bool skip_attn = false, skip_stats = false;
 #endif
   const bool pre_fused = m->layers >= 1 && !no_prefuse;
-  if (pre_fused) TRY(ln(w.X, D, nullptr, m->lnpre_g, m->lnpre_b, w.Xn, D, w.X, D, R, D, pr, stream, 0, m->layer[0].ln1_g, m->layer[0].ln1_b));
+  // The residual stream as a 16-bit pair (inference, big batches, every block's LayerNorms folded): between ln_pre and the last
+  // block the stream exists only as hi = h16(x) - which IS the operand of the GEMM consuming the fold (Xn) - and lo = fp16(x - hi)
+  // (Xlo); out_proj / fc2 read and write the pair (8 bytes per element through their epilogue instead of 10).  Block 0's operand
+  // is the NORMALISED stream (norm1 is fused into ln_pre's pass), so its hi half parks in HID until fc1 overwrites that; the last
+  // block works on fp32 CLS rows again (join_rows).  |x - hi - lo| <= 2^-22 |x|.  GAVA_PAIR_STREAM=0: the fp32 stream (A/B).
+  const bool pair = !saved_x && pre_fused && !no_lastfold && pair_stream(m);
+  if (pre_fused) TRY(ln(w.X, D, nullptr, m->lnpre_g, m->lnpre_b, w.Xn, D, pair ? nullptr : w.X, D, R, D, pr, stream, 0, m->layer[0].ln1_g, m->layer[0].ln1_b,
+                        pair ? w.HID : nullptr, pair ? w.Xlo : nullptr, D));
   else TRY(ln(w.X, D, nullptr, m->lnpre_g, m->lnpre_b, nullptr, 0, w.X, D, R, D, pr, stream));
 
   // ---- blocks (VitaCLIP_vision_encoder.py:115-121, VitaCLIP_vision_encoder_utils.py:155-203)
@@ -337,6 +366,7 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
     if (k == 1) { g_probe.n = i + 1; g_probe.valid |= 1ull << i; }
     return GAVA_OK;
   };
+  auto not_last_blk = [&](int i) { return i + 1 < m->layers; };
   for (int i = 0; i < m->layers; ++i) {
     const gava_vision_layer& L = m->layer[i];
     TRY(keep(1 + i));
@@ -349,8 +379,14 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       if (hipEventRecord(g_side.fork[i], s) != hipSuccess || hipStreamWaitEvent(g_side.s, g_side.fork[i], 0) != hipSuccess)
         return GAVA_ELAUNCH;
     }
-    TRY(ln(w.X, fs, nullptr, nullptr, nullptr, w.CLS16, D, nullptr, 0, BT, D, pr, ss));
-    TRY(gemm_x(wl, w.CLS16, D, L.w_cls, D, L.b_cls, w.CP, D, BT, D, D, GAVA_EPI_F32, pr, ss));
+    // the CLS rows as cls_proj's operand: h16 of the stream - with the pair, its hi half where it lies
+    const void* hi_in = i == 0 ? w.HID : w.Xn;
+    if (pair) {
+      TRY(gemm_x(wl, hi_in, fs, L.w_cls, D, L.b_cls, w.CP, D, BT, D, D, GAVA_EPI_F32, pr, ss));
+    } else {
+      TRY(ln(w.X, fs, nullptr, nullptr, nullptr, w.CLS16, D, nullptr, 0, BT, D, pr, ss));
+      TRY(gemm_x(wl, w.CLS16, D, L.w_cls, D, L.b_cls, w.CP, D, BT, D, D, GAVA_EPI_F32, pr, ss));
+    }
     TRY(ln(w.CP, D, nullptr, L.sln_g, L.sln_b, w.CPn, D, nullptr, 0, BT, D, pr, ss));
     TRY(gemm_x(wl, w.CPn, D, L.w_sqkv, D, L.b_sqkv, w.SQKV, 3 * D, BT, 3 * D, D, GAVA_EPI_H16, pr, ss, nullptr, 0, D, 0.125f));
     {
@@ -380,6 +416,7 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
     static const bool fused_env = !(getenv("GAVA_FUSED_STATS") && getenv("GAVA_FUSED_STATS")[0] == '0');
     const bool fused = fused_env && R >= 8192 && D % 256 == 0 && D <= 1024 && D >= 256;
     Fold produce; produce.x16 = w.Xn; produce.ld_x16 = D; produce.rowsum = w.RSUM; produce.reduced = fused ? 1 : 0;
+    if (pair) { produce.rlo = w.Xlo; produce.xlo = w.Xlo; }
     auto consume = [&](const float* s_, const float* t_) {
       Fold c; c.s = s_; c.t = t_;
       if (fused) c.partials = w.RSUM; else c.stats = w.STATS;
@@ -413,6 +450,10 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       TRY(mark(GAVA_PROBE_OUT, i, 0));
       if (fold2) {
         Lo8 po; if (L8) { po.x8 = w.Xn8; po.ldx8 = 2 * D; }      // out_proj: 16-bit lo product, bf8 copy of x16 for fc1
+        if (pair) {
+          produce.r16 = hi_in;
+          TRY(gemm_x(wl, w.MIX, D, L.w_out, D, L.b_out, nullptr, 0, R, D, D, GAVA_EPI_F32, pr, stream, nullptr, D, 0, 1.f, 0, nullptr, &produce));
+        } else
         TRY(gemm_x(wl, w.MIX, D, L.w_out, D, L.b_out, w.X, D, R, D, D, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce, 0, L8 ? &po : nullptr));
         TRY(mark(GAVA_PROBE_OUT, i, 1));
         if (!skip_stats && !fused) TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
@@ -435,6 +476,10 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       if (f2_8) { f2.A8 = w.HID8; f2.W8 = L8->w_fc28; f2.exp = L8->fc2_exp; }
       if (fold1_next) {
         if (L8) { f2.x8 = w.Xn8; f2.ldx8 = 2 * D; }
+        if (pair) {
+          produce.r16 = w.Xn;
+          TRY(gemm_x(wl, w.HID, F, L.w_fc2, F, L.b_fc2, nullptr, 0, R, D, F, GAVA_EPI_F32, pr, stream, nullptr, D, 0, 1.f, 0, nullptr, &produce));
+        } else
         TRY(gemm_x(wl, w.HID, F, L.w_fc2, F, L.b_fc2, w.X, D, R, D, F, GAVA_EPI_F32, pr, stream, w.X, D, 0, 1.f, 0, nullptr, &produce, 0, L8 ? &f2 : nullptr));
         TRY(mark(GAVA_PROBE_FC2, i, 1));
         if (!skip_stats && !fused) TRY(gava_row_stats(w.RSUM, D / 64, D, R, w.STATS, stream));
@@ -448,6 +493,7 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       // takes x[:,0]; the summary token comes from the prompt path above).  Keys/values are still
       // needed for every token, queries / out_proj / MLP only for the B*T CLS rows: same results,
       // 1/197 of the row work.
+      if (pair) TRY(gava::join_rows(w.Xn, w.Xlo, fs, w.X, fs, BT, D, pr, s));      // those rows as fp32 again
       if (fold1) {   // norm1 folded into the K/V GEMM: Xn holds the 16-bit copy of the un-normalised stream
         Fold c = consume((L8 ? L8->qkv_fold_s8 : L.qkv_fold_s) + D, L.qkv_fold_t + D);
         Lo8 lo; if (L8) { lo.A8 = w.Xn8; lo.W8 = (const char*)L8->w_qkv_fold8 + (size_t)D * 4 * D; lo.exp = L8->qkv_fold_exp; }
@@ -485,7 +531,10 @@ extern "C" int gava_vision_forward_train(const gava_vision_model* m, const float
       TRY(gemm_x(sp ? 0 : wl, w.XNC, S * D, sp ? L.w_fc1_split : L.w_fc1, S * D, L.b_fc1, w.HIDC, S * F, BT, F, S * D, GAVA_EPI_H16_QGELU, pr, stream, nullptr, 0, 0, 1.f, sp));
       TRY(gemm_x(sp ? 0 : wl, w.HIDC, S * F, sp ? L.w_fc2_split : L.w_fc2, S * F, L.b_fc2, w.X, fs, BT, D, S * F, GAVA_EPI_F32, pr, stream, w.X, fs));
     }
-    if (debug_cls) TRY(gava::copy_rows(w.X, fs, debug_cls + (long)i * BT * D, BT, D, s));
+    if (debug_cls) {
+      if (pair && not_last_blk(i)) TRY(gava::join_rows(w.Xn, w.Xlo, fs, debug_cls + (long)i * BT * D, D, BT, D, pr, s));
+      else TRY(gava::copy_rows(w.X, fs, debug_cls + (long)i * BT * D, BT, D, s));
+    }
   }
 
   TRY(keep(1 + m->layers));

@@ -89,6 +89,9 @@ struct GemmParams {
   const unsigned char* A8; const unsigned char* W8; int nk8; unsigned scale8;
   unsigned char* out8; long ldo8;   // L8, 16-bit-output epilogues: bf8 copy of the output rows
   unsigned char* x8; long ldx8;     // L8, producers: bf8 copy of x16
+  // HL instantiations (gava_gemm_args.resid16): the residual stream as a 16-bit pair - r16 / rlo in (pitch ldr), x16 / xlo out
+  // (pitch ldx16); hi in the operand type, lo = fp16(x - hi)
+  const unsigned short* r16; const unsigned short* rlo; unsigned short* xlo;
 };
 
 static __device__ __forceinline__ float aux_up(unsigned short u, int f16) {
@@ -465,10 +468,11 @@ int launch_tile(GemmParams gp, int epi, hipStream_t s) {
 // through the tile switch.  The remap sits on the staging SOURCE rows: the accumulator layout - and with it every epilogue - is
 // the default loop's.  Measured (tools/gemm_vs_vendor.py, non-persistent first version): 4096^3 1264 vs 1122 TF/s, K = 3072 at
 // M = 100864 1165 vs 1108 (vendor 1100).  K % 128 == 0, K >= 256.
-template <class P, int EPI, bool RES, bool SPLIT, bool FOLD = false, bool ALIGN = false, int L8 = 0, bool PP = false>
+template <class P, int EPI, bool RES, bool SPLIT, bool FOLD = false, bool ALIGN = false, int L8 = 0, bool PP = false, bool HL = false>
 __global__ __launch_bounds__(512, 2)
 void gemm256_kernel(const GemmParams p) {
   static_assert(!(PP && L8 == 2), "the ping-pong loop has no 8-bit stages");
+  static_assert(!HL || (PP && RES && EPI == GAVA_EPI_F32 && !L8 && !FOLD && !SPLIT), "HL: the residual producers on the ping-pong loop");
   constexpr int BM = 256, BN = 256, NW = 8;
   constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;   // 32 KiB, 64 KiB
   constexpr int PPW = (BM + BN) / 8 / NW;                            // 8 glds per wave per stage
@@ -483,7 +487,13 @@ void gemm256_kernel(const GemmParams p) {
   // columns 16*jj + 4*fg + r, so that the four lanes of a row write / read 64 contiguous bytes per instruction - with the
   // permuted order every fp32 store and residual load touched 64 separate 16-byte pieces and the fc2 epilogue took
   // 30-50 k cycles per tile (tools/gemm_stamps.py fc2), four times the QuickGELU epilogue of fc1.
-  constexpr bool NAT = GAVA_V3_NAT && (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH);
+  // HL (the stream as a 16-bit hi / lo pair): nothing leaves as fp32 - the permuted order of the 16-bit outputs, a lane's 16 consecutive
+  // columns are 32 contiguous bytes of hi and 32 of lo, the four lanes of a row fill a 128-byte line of each with two instructions
+  // (its own column order - lane (fr, fg) holds columns 32 (jj >> 1) + 8 fg + 4 (jj & 1) + r of its wave's 64: the fragment reads
+  // of the permuted order on W rows staged in natural order - so that the four lanes of a row move 64 CONTIGUOUS bytes of hi, or
+  // of lo, per instruction, like the fp32 form does; with the permuted order's 16 consecutive columns per lane an instruction
+  // touched four 16-byte pieces 32 bytes apart in every row)
+  constexpr bool NAT = GAVA_V3_NAT && (EPI == GAVA_EPI_F32 || EPI == GAVA_EPI_F32_PATCH) && !HL;
   constexpr int CJ = NAT ? 16 : 4;        // column step between a lane's accumulators jj and jj+1
   constexpr int CF = NAT ? 4 : 16;        // column step between the lane groups fg and fg+1
   constexpr int WJ = NAT ? 2048 : 512;    // LDS byte step between the W fragments jj and jj+1
@@ -496,13 +506,14 @@ void gemm256_kernel(const GemmParams p) {
   // (16 rows x 128 B, 16-byte chunks XOR-swizzled by (row >> 1) & 7: conflict-free for the 8-byte writes and the 16-byte
   // reads) so that it leaves as 128 contiguous bytes per row - 2 store instructions touching 16 lines instead of 4
   // touching 64
-  constexpr bool X16_STAGE = EPI == GAVA_EPI_F32;
+  constexpr bool X16_STAGE = EPI == GAVA_EPI_F32 && !HL;
+  constexpr bool ROWSUM = EPI == GAVA_EPI_F32;       // (sum, sum^2) partials of the row groups: the PS block below
   constexpr int XS_PITCH = 128, XS_WAVE = 16 * XS_PITCH;
   // consumers in "partials" mode (p.fpart): (mean, rstd) pairs of the tile's 256 rows, shared by the workgroup, by tile parity
   constexpr int PAIRS_OFF = 2 * STAGE + 2 * FOLD_BYTES, PAIRS_BYTES = 2 * 256 * 8;
   // producers with p.rowsum_reduced: the four waves of a row half leave their (sum, sum^2) per row here [wr][row][wc]
-  constexpr int PS_OFF = 2 * STAGE + NW * XS_WAVE, PS_BYTES = 2 * 128 * 4 * 8;
-  constexpr int TAIL_LDS = (CAN_FOLD ? 2 * FOLD_BYTES + PAIRS_BYTES : 0) + (X16_STAGE ? NW * XS_WAVE + PS_BYTES : 0);
+  constexpr int PS_OFF = 2 * STAGE + (X16_STAGE ? NW * XS_WAVE : 0), PS_BYTES = 2 * 128 * 4 * 8;
+  constexpr int TAIL_LDS = (CAN_FOLD ? 2 * FOLD_BYTES + PAIRS_BYTES : 0) + (X16_STAGE ? NW * XS_WAVE : 0) + (ROWSUM ? PS_BYTES : 0);
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + TAIL_LDS];
   constexpr bool fold = FOLD;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -575,7 +586,7 @@ void gemm256_kernel(const GemmParams p) {
             src[2 * sl + i] = ((unsigned)gm * (unsigned)p.lda + (((ln & 7) ^ ((lr >> 1) & 7)) * 8)) * 2u;
           } else {
             const int ni = sl - 1;
-            const int wrow = NAT ? (lr >> 5) * 64 + ni * 32 + (lr & 31) : (lr >> 5) * 64 + 16 * ((lr >> 3) & 3) + 8 * ni + (lr & 7);
+            const int wrow = (NAT || HL) ? (lr >> 5) * 64 + ni * 32 + (lr & 31) : (lr >> 5) * 64 + 16 * ((lr >> 3) & 3) + 8 * ni + (lr & 7);
             const int sw = NAT ? ((lr >> 1) & 7) : (((lr >> 1) & 1) | (((lr >> 3) & 3) << 1));
             src[2 * sl + i] = ((unsigned)(n0 + wrow) * (unsigned)p.ldw + (((ln & 7) ^ sw) * 8)) * 2u;
           }
@@ -671,9 +682,38 @@ void gemm256_kernel(const GemmParams p) {
   auto load_resid = [&](int i, int mm0, int nn0) {
     int m = mm0 + wr * 128 + i * 16 + fr;
     m = m < p.M ? m : p.M - 1;
+    if (HL) {
+      // the raw pair: 8 registers of hi, 8 of lo, parked in the 16 accumulator registers they will become (resid_up)
+      const long off = (long)m * p.ldr + nn0 + wc * 64 + 8 * fg;       // columns 8 fg .. + 7 and 32 + 8 fg .. + 7 of the wave's 64
+      acc[i][0] = *reinterpret_cast<const f32x4_t*>(p.r16 + off);
+      acc[i][1] = *reinterpret_cast<const f32x4_t*>(p.r16 + off + 32);
+      acc[i][2] = *reinterpret_cast<const f32x4_t*>(p.rlo + off);
+      acc[i][3] = *reinterpret_cast<const f32x4_t*>(p.rlo + off + 32);
+      return;
+    }
     const float* rp = p.resid + (long)m * p.ldr + nn0 + wc * 64 + CF * fg;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) acc[i][jj] = *reinterpret_cast<const f32x4_t*>(rp + CJ * jj);
+  };
+  // HL: the parked pairs -> fp32 accumulators, acc[i][jj][r] = hi + lo of column 32 (jj >> 1) + 8 fg + 4 (jj & 1) + r; called once per tile, when the
+  // loads have landed (the first wait of the tile) and before its first MFMA
+  auto resid_up = [&]() {
+    if (HL) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t h0 = __builtin_bit_cast(u32x4_t, acc[i][0]), h1 = __builtin_bit_cast(u32x4_t, acc[i][1]);
+        const u32x4_t l0 = __builtin_bit_cast(u32x4_t, acc[i][2]), l1 = __builtin_bit_cast(u32x4_t, acc[i][3]);
+        const unsigned hw[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        const unsigned lw[8] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          acc[i][jj] = (f32x4_t){P::up((unsigned short)hw[2 * jj]) + PrecF16::up((unsigned short)lw[2 * jj]),
+                                 P::up((unsigned short)(hw[2 * jj] >> 16)) + PrecF16::up((unsigned short)(lw[2 * jj] >> 16)),
+                                 P::up((unsigned short)hw[2 * jj + 1]) + PrecF16::up((unsigned short)lw[2 * jj + 1]),
+                                 P::up((unsigned short)(hw[2 * jj + 1] >> 16)) + PrecF16::up((unsigned short)(lw[2 * jj + 1] >> 16))};
+      }
+    }
   };
 
   // accumulators of tile `tj` start at -mean_m * s_n: the MFMAs then leave x.W' - mean * s, the epilogue scales by rstd.
@@ -736,7 +776,7 @@ void gemm256_kernel(const GemmParams p) {
   // producers with p.rowsum_reduced: (sum, sum^2) of a row over this tile's 256 columns = the four waves' partials in a
   // fixed order, one float2 per row and 256-column tile: rowsum[row][4]
   auto flush_rowsum = [&](int mm0, int nn0) {
-    if (X16_STAGE && tid < 256) {
+    if (ROWSUM && tid < 256) {
       const float4* q = reinterpret_cast<const float4*>(smem + PS_OFF + tid * 32);
       const float4 a = q[0], b = q[1];
       const int m = mm0 + tid;
@@ -775,6 +815,7 @@ void gemm256_kernel(const GemmParams p) {
     // half-tiles 0, 1 (and the residual tile, older) have landed; the barrier publishes them; then group 1 falls one barrier behind
     if (!CAN_FOLD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    resid_up();
     if (wr == 1) __builtin_amdgcn_s_barrier();
   }
   int counted = 0;   // the next wait may leave this wave's NSTORE (1) or 2*NSTORE (2: pre-activation copy) epilogue stores in flight
@@ -817,7 +858,7 @@ void gemm256_kernel(const GemmParams p) {
       if (kt == 0 && p.dbg && lane == 0 && (wave & 3) == 0 && j < 10) p.dbg[((size_t)blockIdx.x * 2 + (wave >> 2)) * 32 + j * 3 + 0] = wall_clock64();
 #endif
       // every wave has left the previous tile's epilogue: its row-sum partials are complete in LDS
-      if (X16_STAGE && p.rowsum_reduced && kt == 0 && j > 0) flush_rowsum(m0p, n0p);
+      if (ROWSUM && p.rowsum_reduced && kt == 0 && j > 0) flush_rowsum(m0p, n0p);
     };
     // LDS-DMA issue is expensive (~100+ cycles per 1 KiB piece beside running MFMAs): the two waves
     // that share a SIMD (w and w+4) issue their 8 pieces half an iteration apart, so one of them
@@ -924,7 +965,8 @@ void gemm256_kernel(const GemmParams p) {
           else wait_vm(8);
           __builtin_amdgcn_s_barrier();
           // every wave of both groups has left the previous tile's epilogue (they ran it side by side): its row-sum partials are complete
-          if (X16_STAGE && p.rowsum_reduced && kt == 0 && q == 0 && j > 0) flush_rowsum(m0p, n0p);
+          if (ROWSUM && p.rowsum_reduced && kt == 0 && q == 0 && j > 0) flush_rowsum(m0p, n0p);
+          if (HL && B == 0 && q == 0 && kt == 0 && j > 0) resid_up();      // the wait above was vmcnt(0): the next tile's pairs are in
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           // ---- MFMA section: quadrant (mi, ni) = (0,0) (0,1) (1,1) (1,0)
@@ -1060,7 +1102,7 @@ void gemm256_kernel(const GemmParams p) {
 #endif
     // ---- epilogue of tile j: lane holds out[m][n .. n+15], m = m0+wr*128+i*16+fr,
     //      n = n0 + wc*64 + 16*fg + 4*jj + r
-    const int nb0 = n0 + wc * 64 + CF * fg;
+    const int nb0 = n0 + wc * 64 + (HL ? 8 : CF) * fg;
     float4 bj[4];
     if (CAN_FOLD) {   // t_n from this tile's fold block (LDS, by hand: see fold_init)
       unsigned a_t = (lane >> 4) * 64u;
@@ -1078,7 +1120,7 @@ void gemm256_kernel(const GemmParams p) {
     } else {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
-        bj[jj] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb0 + CJ * jj) : make_float4(0, 0, 0, 0);
+        bj[jj] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb0 + (HL ? 32 * (jj >> 1) + 4 * (jj & 1) : CJ * jj)) : make_float4(0, 0, 0, 0);
     }
     // One explicit use on the common path: the compiler waits for the bias HERE, once.  Without it every row
     // below (a basic block of its own behind `m < M`) re-waits with vmcnt(0), i.e. for the previous row's stores.
@@ -1186,6 +1228,25 @@ void gemm256_kernel(const GemmParams p) {
               }
             }
           }
+        } else if (HL) {
+          // the stream leaves as the pair: hi = h16(v), the operand of the GEMM that consumes the fold, and lo = fp16(v - hi)
+          unsigned short* ho = p.x16 + orow * p.ldx16 + nb0;
+          unsigned short* lp = p.xlo + orow * p.ldx16 + nb0;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            uint2 ha, la, hb, lb;
+            split4_lo16<P>(v[8 * h], v[8 * h + 1], v[8 * h + 2], v[8 * h + 3], ha, la);
+            split4_lo16<P>(v[8 * h + 4], v[8 * h + 5], v[8 * h + 6], v[8 * h + 7], hb, lb);
+            *reinterpret_cast<uint4*>(ho + 32 * h) = make_uint4(ha.x, ha.y, hb.x, hb.y);
+            *reinterpret_cast<uint4*>(lp + 32 * h) = make_uint4(la.x, la.y, lb.x, lb.y);
+          }
+          float ps1 = 0.f, ps2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { ps1 += v[e]; ps2 += v[e] * v[e]; }
+          ps1 = sum_across_lane_groups(ps1); ps2 = sum_across_lane_groups(ps2);
+          if (p.rowsum_reduced) {
+            if (fg == 0) *reinterpret_cast<float2*>(smem + PS_OFF + ((wr * 128 + i * 16 + fr) * 4 + wc) * 8) = make_float2(ps1, ps2);
+          } else if (fg == 0) p.rowsum[orow * (p.N / 64) + (n0 + wc * 64) / 64] = make_float2(ps1, ps2);
         } else {
           float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + nb0;
           if (EPI == GAVA_EPI_F32_PATCH) {
@@ -1276,7 +1337,7 @@ void gemm256_kernel(const GemmParams p) {
     m0p = m0; n0p = n0;
     m0 = m0n; n0 = n0n;
   }
-  if (X16_STAGE && p.rowsum_reduced) {
+  if (ROWSUM && p.rowsum_reduced) {
     __syncthreads();
     flush_rowsum(m0p, n0p);
   }
@@ -1360,6 +1421,15 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
   if (epi == GAVA_EPI_F32) {
     const int a_sm = aligned_walk_sm(gp.tiles_m, gp.tiles_n, gp.sn, blocks, avail);
     if (a_sm) { align = true; gp.sm = a_sm; }
+  }
+  // the residual stream as a 16-bit pair (HL instantiations): the ping-pong loop only
+  if (gp.r16) {
+    const bool can_pp = gp.K % 128 == 0 && (gp.w_lo == 1 ? 2 : 1) * gp.K >= 256 && !gp.split_out && !gp.aux_out && !gp.aux;
+    if (epi != GAVA_EPI_F32 || !can_pp || KERN != 3 || gp.w_lo == 2 || gp.out8 || gp.x8) return GAVA_EINVAL;
+    if (align) hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, true, false, false, true, 0, true, true>), grid, block, 0, s, gp);
+    else hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, true, false, false, false, 0, true, true>), grid, block, 0, s, gp);
+    GAVA_CHECK_LAUNCH();
+    return GAVA_OK;
   }
   // the 8-bit lo product / the bf8 copies: fp16 operands, the four per-block GEMMs of the vision tower in the forms the
   // inference driver launches them (LayerNorm-folded consumers, residual producers); anything else is rejected
@@ -1748,6 +1818,11 @@ int launch_pair(GemmParams gp, hipStream_t s) {
 template <class P>
 int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   static const int variant = getenv("GAVA_GEMM_VARIANT") ? atoi(getenv("GAVA_GEMM_VARIANT")) : 0;
+  if (gp.r16) {   // the 16-bit residual pair: the persistent 256^2 kernel's ping-pong loop only; never fall back silently
+    const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
+    if ((gp.kernel != GAVA_KERNEL_AUTO && gp.kernel != GAVA_KERNEL_PP) || gp.N % 256 || !fits || gp.frames || gp.clips) return GAVA_EINVAL;
+    return launch_256<P, 3>(gp, epi, s);
+  }
   if (gp.w_lo == 2 || gp.out8 || gp.x8) {   // only the persistent 256^2 kernel implements these; never fall back silently
     const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
     if (gp.kernel == GAVA_KERNEL_PAIR || gp.N % 256 || !fits || gp.frames || gp.clips) return GAVA_EINVAL;
@@ -1807,6 +1882,16 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
 
 }  // namespace
 
+namespace gava {
+// the conditions of launch_prec / launch_256 for the HL instantiations; GAVA_PAIR_STREAM=0: never (A/B against the fp32 stream)
+bool gemm_takes_pair(int M, int N, int K, long lda, long ldw) {
+  const char* e = getenv("GAVA_PAIR_STREAM");      // read per call: the tests switch it inside one process
+  const bool on = !(e && e[0] == '0');
+  const bool fits = (unsigned long long)M * lda < (1ull << 31) && (unsigned long long)N * ldw < (1ull << 31);
+  return on && M > 0 && N % 256 == 0 && N <= 1024 && K % 128 == 0 && K >= 256 && fits;
+}
+}  // namespace gava
+
 extern "C" int gava_gemm_aligned_walk(int M, int N, int cu_reserve) {
   if (M <= 0 || N <= 0 || N % 256) return 0;
   const int n_cu = persistent_cus();
@@ -1822,7 +1907,12 @@ extern "C" int gava_gemm_aligned_walk(int M, int N, int cu_reserve) {
 extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   const bool patch_u8 = a && a->epilogue == GAVA_EPI_F32_PATCH && !a->A && !a->frames && a->clips;
   const bool patch_direct = a && a->epilogue == GAVA_EPI_F32_PATCH && !a->A && (a->frames || patch_u8);
-  if (!a || (!a->A && !patch_direct) || !a->W || !a->out) return GAVA_EINVAL;
+  const bool hl = a && a->resid16 != nullptr;
+  if (!a || (!a->A && !patch_direct) || !a->W || (!a->out && !hl)) return GAVA_EINVAL;
+  if (hl && (a->epilogue != GAVA_EPI_F32 || a->out || a->resid || !a->resid_lo || !a->x16_out || !a->xlo_out || !a->rowsum_out ||
+             a->ldr % 8 || a->ldr < a->N || a->ld_x16 < a->N || a->w_lo == 2 || a->out8 || a->x8_out || a->K % 128 ||
+             (((uintptr_t)a->resid16 | (uintptr_t)a->resid_lo | (uintptr_t)a->xlo_out) & 15))) return GAVA_EINVAL;
+  if (!hl && (a->resid_lo || a->xlo_out)) return GAVA_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return GAVA_EINVAL;
   if (a->N % 128 || a->K % BK) return GAVA_EINVAL;
   if (a->w_lo < 0 || a->w_lo > 2) return GAVA_EINVAL;
@@ -1843,7 +1933,7 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   if (((uintptr_t)a->W | (uintptr_t)a->out) & 15) return GAVA_EINVAL;
   if (a->A && ((uintptr_t)a->A & 15)) return GAVA_EINVAL;
   if (a->bias && ((uintptr_t)a->bias & 15)) return GAVA_EINVAL;
-  if (a->ldo % 4 || a->ldo < (a->split_out ? 3 : 1) * (int64_t)a->N) return GAVA_EINVAL;
+  if (!hl && (a->ldo % 4 || a->ldo < (a->split_out ? 3 : 1) * (int64_t)a->N)) return GAVA_EINVAL;
   if (a->split_out && a->epilogue != GAVA_EPI_H16 && a->epilogue != GAVA_EPI_H16_QGELU) return GAVA_EINVAL;
   if (a->epilogue == GAVA_EPI_H16_QGELU_BWD && (!a->aux || ((uintptr_t)a->aux & 15) || a->ldo % 8 ||
                                                (a->aux_prec != GAVA_PREC_F16 && a->aux_prec != GAVA_PREC_BF16))) return GAVA_EINVAL;
@@ -1883,6 +1973,7 @@ extern "C" int gava_gemm(const gava_gemm_args* a, gava_stream_t stream) {
   gp.nk8 = a->w_lo == 2 ? a->K / 128 : 0;
   gp.scale8 = 0x01010101u * (unsigned)(127 - a->w8_exp);
   gp.out8 = (unsigned char*)a->out8; gp.ldo8 = a->ldo8; gp.x8 = (unsigned char*)a->x8_out; gp.ldx8 = a->ld_x8;
+  gp.r16 = (const unsigned short*)a->resid16; gp.rlo = (const unsigned short*)a->resid_lo; gp.xlo = (unsigned short*)a->xlo_out;
 #ifdef GAVA_ENABLE_ABLATE   // timing-probe builds only (tools/ab_build.sh NAME -DGAVA_ENABLE_ABLATE): results are WRONG by design
   static const int ablate = getenv("GAVA_GEMM_ABLATE") ? atoi(getenv("GAVA_GEMM_ABLATE")) : 0;
   gp.ablate = ablate;

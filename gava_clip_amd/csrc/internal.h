@@ -9,6 +9,10 @@ int cls_embed(float* X, const float* cls, const float* pos, const float* time, i
               long frame_stride, hipStream_t s);
 int mean_rows(const float* in, float* out, int B, int T, int D, hipStream_t s);
 int copy_rows(const float* in, long in_stride, float* out, int rows, int D, hipStream_t s);
+// fp32 rows = hi + lo of the residual stream's 16-bit pair (rows in_stride elements apart)
+int join_rows(const void* hi, const void* lo, long in_stride, float* out, long out_stride, int rows, int D, int prec, hipStream_t s);
+// gemm.hip: does gava_gemm take an EPI_F32 GEMM of this shape with the residual as a 16-bit pair (gava_gemm_args.resid16)?
+bool gemm_takes_pair(int M, int N, int K, long lda, long ldw);
 int text_embed(const float* emb, const float* pos, const float* ctx, const int* tok, float* X,
                int n_prompts, int L, int W, int n_ctx, hipStream_t s);
 unsigned long long* debug_buffer();   // set by gava_debug_set_buffer; nullptr = stamps off

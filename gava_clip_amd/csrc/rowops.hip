@@ -43,6 +43,7 @@ struct LnParams {
   float* out32; long o32_stride;
   int rows, D, split;
   const float* gamma2; const float* beta2;
+  unsigned short* out_hi; unsigned short* out_lo; long ohl_stride;   // 16-bit pair of what out32 receives
 };
 
 template <class P>
@@ -76,7 +77,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
     // second LayerNorm on the first one's result: out32 gets the first, out16 the second
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
-      if (act[i] && p.out32) *reinterpret_cast<float4*>(p.out32 + (long)row * p.o32_stride + (lane + 64 * i) * 4) = v[i];
+      if (act[i]) {
+        const int c = (lane + 64 * i) * 4;
+        if (p.out32) *reinterpret_cast<float4*>(p.out32 + (long)row * p.o32_stride + c) = v[i];
+        if (p.out_hi) {
+          uint2 hi, lo;
+          split4_lo16<P>(v[i].x, v[i].y, v[i].z, v[i].w, hi, lo);
+          *reinterpret_cast<uint2*>(p.out_hi + (long)row * p.ohl_stride + c) = hi;
+          *reinterpret_cast<uint2*>(p.out_lo + (long)row * p.ohl_stride + c) = lo;
+        }
+      }
     ln_row(v, 0, p.D, act);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
@@ -105,6 +115,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
         }
       }
       if (p.out32 && !p.gamma2) *reinterpret_cast<float4*>(p.out32 + (long)row * p.o32_stride + c) = v[i];
+      if (p.out_hi && !p.gamma2) {
+        uint2 hi, lo;
+        split4_lo16<P>(v[i].x, v[i].y, v[i].z, v[i].w, hi, lo);
+        *reinterpret_cast<uint2*>(p.out_hi + (long)row * p.ohl_stride + c) = hi;
+        *reinterpret_cast<uint2*>(p.out_lo + (long)row * p.ohl_stride + c) = lo;
+      }
     }
 }
 
@@ -174,6 +190,16 @@ __global__ void mean_rows_kernel(const float* in, float* out, int B, int T, int 
   float s = 0.f;
   for (int t = 0; t < T; ++t) s += in[(b * T + t) * D + c];
   out[id] = s / (float)T;
+}
+
+// fp32 rows out of the stream's 16-bit pair (gava_gemm_args.resid16): out = hi + lo; the B*T CLS rows the last block works on, debug taps
+template <class P>
+__global__ void join_rows_kernel(const unsigned short* hi, const unsigned short* lo, long in_stride, float* out, long out_stride,
+                                 int rows, int D) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)rows * D) return;
+  const long r = id / D, c = id % D;
+  out[r * out_stride + c] = P::up(hi[r * in_stride + c]) + PrecF16::up(lo[r * in_stride + c]);
 }
 
 // copy strided rows (debug taps)
@@ -313,13 +339,15 @@ extern "C" int gava_row_stats(const float* rowsum, int slots, int D, int rows, f
 extern "C" int gava_layernorm(const gava_layernorm_args* a, gava_stream_t stream) {
   if (!a || !a->in || a->rows <= 0) return GAVA_EINVAL;
   if (a->D % 4 || a->D > 256 * MAXV || a->D <= 0) return GAVA_EINVAL;
-  if (!a->out16 && !a->out32) return GAVA_EINVAL;
+  if (!a->out16 && !a->out32 && !a->out_hi) return GAVA_EINVAL;
+  if ((a->out_hi != nullptr) != (a->out_lo != nullptr) || (a->out_hi && (a->out_hl_stride % 4 || a->out_hl_stride < a->D))) return GAVA_EINVAL;
   if (a->split_out && (!a->out16 || a->out16_stride < 3 * (int64_t)a->D)) return GAVA_EINVAL;
   if (a->gamma && !a->beta) return GAVA_EINVAL;
-  if ((a->gamma2 != nullptr) != (a->beta2 != nullptr) || (a->gamma2 && (!a->gamma || !a->out16 || !a->out32))) return GAVA_EINVAL;
+  if ((a->gamma2 != nullptr) != (a->beta2 != nullptr) || (a->gamma2 && (!a->gamma || !a->out16 || (!a->out32 && !a->out_hi)))) return GAVA_EINVAL;
   if (a->in_stride % 4 || (a->out16 && a->out16_stride % 4) || (a->out32 && a->out32_stride % 4)) return GAVA_EINVAL;
   LnParams p{a->in, a->in_stride, a->in_row_index, a->gamma, a->beta, (unsigned short*)a->out16,
-             a->out16_stride, a->out32, a->out32_stride, a->rows, a->D, a->split_out, a->gamma2, a->beta2};
+             a->out16_stride, a->out32, a->out32_stride, a->rows, a->D, a->split_out, a->gamma2, a->beta2,
+             (unsigned short*)a->out_hi, (unsigned short*)a->out_lo, a->out_hl_stride};
   dim3 grid((a->rows + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (a->prec == GAVA_PREC_F16) hipLaunchKernelGGL(layernorm_kernel<PrecF16>, grid, block, 0, s, p);
@@ -400,6 +428,18 @@ int mean_rows(const float* in, float* out, int B, int T, int D, hipStream_t s) {
 int copy_rows(const float* in, long in_stride, float* out, int rows, int D, hipStream_t s) {
   const long n = (long)rows * D;
   hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, in_stride, out, rows, D);
+  GAVA_CHECK_LAUNCH();
+  return GAVA_OK;
+}
+
+int join_rows(const void* hi, const void* lo, long in_stride, float* out, long out_stride, int rows, int D, int prec, hipStream_t s) {
+  const long n = (long)rows * D;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (prec == GAVA_PREC_F16)
+    hipLaunchKernelGGL(join_rows_kernel<PrecF16>, grid, block, 0, s, (const unsigned short*)hi, (const unsigned short*)lo, in_stride, out, out_stride, rows, D);
+  else if (prec == GAVA_PREC_BF16)
+    hipLaunchKernelGGL(join_rows_kernel<PrecBF16>, grid, block, 0, s, (const unsigned short*)hi, (const unsigned short*)lo, in_stride, out, out_stride, rows, D);
+  else return GAVA_EINVAL;
   GAVA_CHECK_LAUNCH();
   return GAVA_OK;
 }

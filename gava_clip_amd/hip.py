@@ -23,7 +23,7 @@ EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_preprocess_clip", "gava_layernorm_backward", "gava_qgelu_backward", "gava_attention_backward",
            "gava_text_forward_train", "gava_vision_forward_train", "gava_attention_backward_workspace_bytes", "gava_vision_forward_keep", "gava_row_stats",
            "gava_probe_fc1_enable", "gava_probe_fc1_read", "gava_clip_geometry", "gava_patchify", "gava_attention_f32",
-           "gava_gemm_aligned_walk"]
+           "gava_gemm_aligned_walk", "gava_vision_pair_stream"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 
@@ -41,14 +41,16 @@ class GemmArgs(C.Structure):
                 ("rowsum_reduced", C.c_int), ("fold_partials", _fp),
                 ("clips", _vp), ("clip_lut", _fp), ("kernel", C.c_int),
                 ("w_lo", C.c_int), ("A8", _vp), ("lda8", C.c_int64), ("W8", _vp), ("ldw8", C.c_int64), ("w8_exp", C.c_int),
-                ("out8", _vp), ("ldo8", C.c_int64), ("x8_out", _vp), ("ld_x8", C.c_int64)]
+                ("out8", _vp), ("ldo8", C.c_int64), ("x8_out", _vp), ("ld_x8", C.c_int64),
+                ("resid16", _vp), ("resid_lo", _vp), ("xlo_out", _vp)]
 
 
 class LayerNormArgs(C.Structure):
     _fields_ = [("inp", _fp), ("in_stride", C.c_int64), ("in_row_index", _ip), ("gamma", _fp), ("beta", _fp),
                 ("out16", _vp), ("out16_stride", C.c_int64), ("out32", _fp), ("out32_stride", C.c_int64),
                 ("rows", C.c_int), ("D", C.c_int), ("prec", C.c_int), ("split_out", C.c_int),
-                ("gamma2", _fp), ("beta2", _fp)]
+                ("gamma2", _fp), ("beta2", _fp),
+                ("out_hi", _vp), ("out_lo", _vp), ("out_hl_stride", C.c_int64)]
 
 
 class AttentionArgs(C.Structure):
@@ -260,8 +262,9 @@ def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0
          pos=None, time=None, n_patches=0, T=0, M=None, split_out=False, frames=None, frame_size=0, patch=0, aux=None,
          aux_prec=None, aux_out=None, x16_out=None, rowsum_out=None, fold_stats=None, fold_s=None, fold_t=None,
          cu_reserve=0, rowsum_reduced=False, fold_partials=None, clips=None, clip_lut=None, kernel=0, w_lo=0, K=None,
-         A8=None, W8=None, w8_exp=0, out8=None, x8_out=None):
+         A8=None, W8=None, w8_exp=0, out8=None, x8_out=None, resid16=None, resid_lo=None, xlo_out=None):
     a = GemmArgs()
+    a.resid16, a.resid_lo, a.xlo_out = ptr(resid16), ptr(resid_lo), ptr(xlo_out)
     a.kernel = kernel
     a.w_lo, a.w8_exp = w_lo, w8_exp
     a.A8, a.lda8, a.W8, a.ldw8 = ptr(A8), (A8.stride(0) if A8 is not None else 0), ptr(W8), (W8.stride(0) if W8 is not None else 0)
@@ -276,8 +279,8 @@ def gemm(A, W, bias, out, *, epilogue, prec, resid=None, scale_cols=0, scale=1.0
     a.aux_prec = prec if aux_prec is None else aux_prec
     a.A, a.lda, a.W, a.ldw = ptr(A), (A.stride(0) if A is not None else W.stride(0)), ptr(W), W.stride(0)
     a.frames, a.frame_size, a.patch = ptr(frames), frame_size, patch
-    a.bias, a.out, a.ldo = ptr(bias), ptr(out), out.stride(0)
-    a.resid, a.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
+    a.bias, a.out, a.ldo = ptr(bias), ptr(out), (out.stride(0) if out is not None else 0)
+    a.resid, a.ldr = ptr(resid), (resid.stride(0) if resid is not None else (resid16.stride(0) if resid16 is not None else 0))
     a.M, a.N, a.K = (A.shape[0] if M is None else M), W.shape[0], (W.shape[1] // (2 if w_lo == 1 else 1) if K is None else K)
     a.epilogue, a.prec, a.scale_cols, a.scale = epilogue, prec, scale_cols, scale
     a.pos, a.time, a.n_patches, a.T = ptr(pos), ptr(time), n_patches, T
@@ -294,8 +297,9 @@ def attention_f32(q, k, v, out, *, batch, heads, L, prec, causal=False, split_ou
 
 
 def layernorm(x, gamma, beta, *, out16=None, out32=None, prec, rows=None, in_stride=None, row_index=None,
-              split_out=False, gamma2=None, beta2=None):
+              split_out=False, gamma2=None, beta2=None, out_hi=None, out_lo=None):
     a = LayerNormArgs()
+    a.out_hi, a.out_lo, a.out_hl_stride = ptr(out_hi), ptr(out_lo), (out_hi.stride(0) if out_hi is not None else 0)
     a.gamma2, a.beta2 = ptr(gamma2), ptr(beta2)
     a.inp, a.in_stride, a.in_row_index = ptr(x), (x.stride(0) if in_stride is None else in_stride), ptr(row_index)
     a.gamma, a.beta = ptr(gamma), ptr(beta)

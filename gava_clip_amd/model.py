@@ -646,6 +646,8 @@ class _HipHost:
         if clips is not None:
             m.clips, m.clip_lut = hip.ptr(desc), hip.ptr(lut)
         nbytes = lib.gava_vision_workspace_bytes(C.byref(m))
+        # (measurement / tests) does the inference driver keep the residual stream of this batch as a 16-bit pair?
+        self.last["pair_stream"] = bool(saved is None and kept is None and lib.gava_vision_pair_stream(C.byref(m)))
         if nbytes == 0:
             raise hip.GavaError(f"unsupported vision shape: B={B} T={T} num_frames={self.num_frames} {sh}")
         ws = self._workspace("vision", nbytes, x.device)

@@ -152,6 +152,15 @@ typedef struct {
   int w_lo;
   const void* A8; int64_t lda8; const void* W8; int64_t ldw8; int w8_exp;
   void* out8; int64_t ldo8; void* x8_out; int64_t ld_x8;
+  /* The residual stream as a 16-bit pair (round 4; inference driver of the vision tower, DESIGN.md "Residual stream").  EPI_F32
+   * with resid16 != NULL: the residual is read as resid16 + resid_lo (both [M][ldr]: hi in the operand type, lo in fp16 whatever
+   * the operand type) and the result x = resid + A W^T + bias leaves as x16_out = h16(x) and xlo_out = fp16(x - h16(x)) (both
+   * [M][ld_x16]) together with the producer's row sums (rowsum_out, computed from the fp32 x): 8 bytes per element through the
+   * epilogue instead of 10 (fp32 in, fp32 out, 16-bit copy), and the hi half IS the operand of the GEMM that consumes the
+   * LayerNorm fold.  |x - hi - lo| <= 2^-22 |x| (fp16 operands; 2^-20 with bf16).  out and resid must be NULL, x16_out /
+   * xlo_out may alias resid16 / resid_lo (every element is read and written by the same lane).  The persistent 256 x 256
+   * kernel with the ping-pong loop only (N % 256 == 0, K % 128 == 0, K >= 256, w_lo <= 1); rejected elsewhere. */
+  const void* resid16; const void* resid_lo; void* xlo_out;
 } gava_gemm_args;
 #define GAVA_KERNEL_AUTO 0
 #define GAVA_KERNEL_256 3
@@ -182,6 +191,10 @@ typedef struct {
    * block 0 (VitaCLIP_vision_encoder.py:113, VitaCLIP_vision_encoder_utils.py:190): one read of the embedding instead
    * of two row passes. */
   const float* gamma2; const float* beta2;
+  /* Optional 16-bit pair of what out32 receives (see gava_gemm_args.resid16): out_hi = h16(y), out_lo = fp16(y - h16(y)),
+   * rows out_hl_stride apart, y = the FIRST LayerNorm's result (or the converted row when gamma == NULL).  Both or neither;
+   * out32 may then be NULL. */
+  void* out_hi; void* out_lo; int64_t out_hl_stride;
 } gava_layernorm_args;
 int gava_layernorm(const gava_layernorm_args* a, gava_stream_t stream);
 
@@ -290,6 +303,10 @@ typedef struct gava_vision_layer8 {
  * summary: fp32 [B][D] (:129-130).  debug_cls (optional): fp32 [layers][B*T_in][D] receives the
  * CLS row of every frame after each block. */
 size_t gava_vision_workspace_bytes(const gava_vision_model* m);
+/* Measurement / test helper: 1 when gava_vision_forward keeps the residual stream of this model and batch as a 16-bit pair
+ * between ln_pre and the last block (gava_gemm_args.resid16: big batches with every block's LayerNorms folded), else 0.  The
+ * decision the driver makes (environment switch GAVA_PAIR_STREAM=0: never). */
+int gava_vision_pair_stream(const gava_vision_model* m);
 int gava_vision_forward(const gava_vision_model* m, const float* x, float* cls_x, float* summary,
                         float* debug_cls, void* workspace, size_t workspace_bytes,
                         gava_stream_t stream);

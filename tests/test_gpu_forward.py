@@ -451,6 +451,43 @@ def test_c2_full_size_batch_is_anchored_to_the_golden_and_deterministic(golden_d
     assert e_small < 5e-4
 
 
+@pytest.mark.parametrize("mode", ["fp16", "bf16", "fp16+wlo"])
+def test_residual_stream_as_16_bit_pair_against_the_fp32_stream(mode):
+    """Big batches keep the residual stream between ln_pre and the last block as a 16-bit pair (hi = h16(x) = the operand of
+    the GEMM consuming the LayerNorm fold, lo = fp16(x - hi); `pair` in csrc/forward.hip).  Same model, same 44-clip batch
+    (R = 69344 rows: the persistent kernels, ragged last tile), GAVA_PAIR_STREAM=0 (fp32 stream) against the default, per-block
+    CLS rows (debug taps: read back out of the pair), video features and logits.  The pair itself is exact to 2^-22 |x| (the op
+    test), but the two forwards are two ROUNDINGS of the same computation: a 1e-7 difference in x flips h16(x) for one element in
+    ~4000, each flip is a 1-ulp (1e-3) change of one operand element, so rows differ by the operands' own rounding noise here and
+    there - a small fraction of the error either path has against the reference (which the full-size fixture tests bound for the
+    default = pair path): the bound here is a quarter of the 1e-3 budget on the maximum and 3e-5 on the median."""
+    cfg = VitaConfig(num_frames=8, num_layers=4, text_layers=2)
+    m, _ = build(cfg, mode)
+    m.debug_taps = True
+    x = torch.from_numpy(synth.synth_clip(44, 8, 224, seed=3)).cuda()
+    out = {}
+    for on in ("1", "0"):
+        os.environ["GAVA_PAIR_STREAM"] = on
+        try:
+            with torch.no_grad():
+                lg = m(x)[0]
+            assert m.last["pair_stream"] == (on == "1")
+            out[on] = (lg.cpu().numpy(), m.last["cls_rows"].cpu().numpy(), m.last["video_features"].cpu().numpy())
+        finally:
+            os.environ.pop("GAVA_PAIR_STREAM", None)
+    k = 8 if mode == "bf16" else 1
+    e = [rel_to_max(a, b) for a, b in zip(out["1"], out["0"])]
+    per_block = [rel_to_max(out["1"][1][i], out["0"][1][i]) for i in range(cfg.num_layers)]
+    med = float(np.median(np.abs(out["1"][1] - out["0"][1])) / np.abs(out["0"][1]).max())
+    print(f"\n[pair vs fp32 stream, {mode}] logits {e[0]:.2e} cls rows {['%.1e' % v for v in per_block]} (median {med:.1e}) video features {e[2]:.2e}")
+    assert max(e[0], e[2]) < 2.5e-4 * k and max(per_block) < 5e-4 * k and med < 3e-5 * k
+    assert not np.array_equal(out["1"][1], out["0"][1])
+    # a small batch runs the fp32 stream whatever the switch says
+    with torch.no_grad():
+        m(x[:2])
+    assert not m.last["pair_stream"]
+
+
 def test_c2_full_batch_vs_the_reference(golden_dir):
     """BASELINE config c2 end to end against the REFERENCE: all 64 clips of a full batch (tests/golden/c2_full.npz, a 64-clip
     reference forward in the build container, tools/gen_golden.py --c2-full).  192 logits under the frozen mixed criterion,

@@ -767,6 +767,96 @@ def test_gemm_ping_pong_kernel(prec, M, N, K):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,D", [(45000, 768), (300, 768), (20000, 1024), (100864, 768)])
+def test_gemm_residual_stream_as_16_bit_pair(prec, M, D):
+    """gava_gemm_args.resid16 (gemm256_kernel<..., HL>): the residual producers reading and writing the stream as hi = h16(x),
+    lo = fp16(x - hi).  Against the fp32-stream kernel on the same inputs (resid = hi + lo, exact in fp32): the hi half is its
+    x16 copy bit for bit (same k order, same fp32 x), the row sums are its row sums to fp32 rounding, hi + lo is its fp32 output to 2^-21 |x|
+    (2^-19 with bf16 operands; never better than 2^-24 absolute: fp16 subnormals), lo bit for bit fp16(x - hi); rows beyond M untouched; in place (out pair = in pair) equals out of place; the aligned and the
+    plain tile walk (M = 100864 / the smaller ones); both K of the forward; the weight-lo pass; what the ABI rejects."""
+    d = dev()
+    dt = hip.h16_dtype(prec)
+    Mp = (M + 255) // 256 * 256
+    rel = 2.0 ** -21 if prec == hip.PREC_F16 else 2.0 ** -19
+    for K in (D, 4 * D):
+        A = rnd((M, K), 1.0, 1).to(d).to(dt)
+        W = rnd((D, K), K ** -0.5, 2).to(d).to(dt)
+        b = rnd((D,), 0.3, 3).to(d)
+        X0 = ((rnd((M, D), 1.0, 4) + 0.5) * 3).to(d)
+        hi0 = X0.to(dt)
+        lo0 = (X0 - hi0.float()).half()
+        Xp = hi0.float() + lo0.float()                      # the stream the pair represents
+        Y = torch.zeros(M, D, device=d)
+        x16 = torch.zeros(Mp, D, dtype=dt, device=d)
+        part = torch.zeros(Mp + 32, 4, 2, dtype=torch.float32, device=d)
+        hip.gemm(A, W, b, Y, epilogue=hip.EPI_F32, prec=prec, resid=Xp, x16_out=x16, rowsum_out=part, rowsum_reduced=True, kernel=hip.KERNEL_PP)
+        hi = torch.full((Mp + 8, D), 7.0, dtype=dt, device=d)
+        lo = torch.full((Mp + 8, D), 7.0, dtype=torch.float16, device=d)
+        part2 = torch.zeros(Mp + 32, 4, 2, dtype=torch.float32, device=d)
+        hip.gemm(A, W, b, None, epilogue=hip.EPI_F32, prec=prec, resid16=hi0, resid_lo=lo0, x16_out=hi, xlo_out=lo, rowsum_out=part2,
+                 rowsum_reduced=True)
+        assert torch.equal(hi[:M], x16[:M]), K
+        # (a lane adds its 16 columns in another order than the fp32-output layout's lane does: equal to fp32 rounding, not bit for bit)
+        assert torch.allclose(part2[:M, :D // 256], part[:M, :D // 256], rtol=2e-6, atol=1e-4), K
+        assert torch.all(hi[M:].float() == 7.0) and torch.all(lo[M:].float() == 7.0)
+        back = hi[:M].float() + lo[:M].float()
+        # (fp16 subnormals below 6.1e-5 are 2^-24 apart: the lo of an |x| < 0.06 carries an absolute error of up to 2^-25)
+        assert bool(((back - Y).abs() <= torch.maximum(rel * Y.abs(), torch.full_like(Y, 2.0 ** -24))).all()), K
+        assert torch.equal(lo[:M], (Y - x16[:M].float()).half()), K
+        # in place
+        hi_ip, lo_ip = hi0.clone(), lo0.clone()
+        if hi_ip.shape[0] < Mp:
+            hi_ip = torch.cat([hi_ip, torch.zeros(Mp - M, D, dtype=dt, device=d)]); lo_ip = torch.cat([lo_ip, torch.zeros(Mp - M, D, dtype=torch.float16, device=d)])
+        hip.gemm(A, W, b, None, epilogue=hip.EPI_F32, prec=prec, resid16=hi_ip, resid_lo=lo_ip, x16_out=hi_ip, xlo_out=lo_ip, rowsum_out=part2,
+                 rowsum_reduced=True, M=M)
+        assert torch.equal(hi_ip[:M], hi[:M]) and torch.equal(lo_ip[:M], lo[:M]), K
+    # weight-lo pass (w_lo = 1) with the pair: against the fp32-stream kernel with the same packed weight
+    K = D
+    A = rnd((M, K), 1.0, 1).to(d).to(dt)
+    Wf = rnd((D, K), K ** -0.5, 2).to(d)
+    Wh = Wf.to(dt)
+    Wp = torch.cat([Wh, (Wf - Wh.float()).to(dt)], 1).contiguous()
+    hip.gemm(A, Wp, b, Y, epilogue=hip.EPI_F32, prec=prec, resid=Xp, x16_out=x16, rowsum_out=part, rowsum_reduced=True, kernel=hip.KERNEL_PP, w_lo=1)
+    hip.gemm(A, Wp, b, None, epilogue=hip.EPI_F32, prec=prec, resid16=hi0, resid_lo=lo0, x16_out=hi, xlo_out=lo, rowsum_out=part2, rowsum_reduced=True, w_lo=1)
+    assert torch.equal(hi[:M], x16[:M]) and torch.allclose(part2[:M, :D // 256], part[:M, :D // 256], rtol=2e-6, atol=1e-4)
+    # rejected: an fp32 output or residual beside the pair, a missing half, a kernel that does not implement it, K % 128
+    kw = dict(epilogue=hip.EPI_F32, prec=prec, rowsum_out=part2, rowsum_reduced=True)
+    for bad in (dict(out=Y, resid16=hi0, resid_lo=lo0, x16_out=hi, xlo_out=lo), dict(out=None, resid=Xp, resid16=hi0, resid_lo=lo0, x16_out=hi, xlo_out=lo),
+                dict(out=None, resid16=hi0, x16_out=hi, xlo_out=lo), dict(out=None, resid16=hi0, resid_lo=lo0, x16_out=hi),
+                dict(out=None, resid16=hi0, resid_lo=lo0, x16_out=hi, xlo_out=lo, kernel=hip.KERNEL_256),
+                dict(out=Y, resid=Xp, x16_out=hi, xlo_out=lo)):
+        with pytest.raises(hip.GavaError):
+            bad = dict(bad); o = bad.pop("out")
+            hip.gemm(A, Wh, b, o, **kw, **bad)
+    with pytest.raises(hip.GavaError):
+        hip.gemm(A[:, :192].contiguous(), Wh[:, :192].contiguous(), b, None, resid16=hi0, resid_lo=lo0, x16_out=hi, xlo_out=lo, **kw)
+
+
+def test_layernorm_and_join_rows_of_the_16_bit_pair():
+    """gava_layernorm_args.out_hi / out_lo: the pair of the FIRST LayerNorm's result beside the fused second one (ln_pre + norm1 of
+    block 0), and of a plain LayerNorm; hi = h16(y) bit for bit, hi + lo = y to 2^-21."""
+    d = dev()
+    for prec in PRECS:
+        dt = hip.h16_dtype(prec)
+        x = (rnd((1000, 768), 2.0, 1) + 0.3).to(d)
+        g1, b1, g2, b2 = ((1 + rnd((768,), 0.2, 2)).to(d), rnd((768,), 0.2, 3).to(d), (1 + rnd((768,), 0.2, 4)).to(d), rnd((768,), 0.2, 5).to(d))
+        y32 = torch.zeros_like(x); o16 = torch.zeros(1000, 768, dtype=dt, device=d)
+        hip.layernorm(x, g1, b1, out16=o16, out32=y32, prec=prec, gamma2=g2, beta2=b2)
+        hi = torch.zeros(1000, 768, dtype=dt, device=d); lo = torch.zeros(1000, 768, dtype=torch.float16, device=d)
+        o16b = torch.zeros_like(o16)
+        hip.layernorm(x, g1, b1, out16=o16b, prec=prec, gamma2=g2, beta2=b2, out_hi=hi, out_lo=lo)
+        assert torch.equal(o16, o16b)
+        assert torch.equal(hi, y32.to(dt))
+        rel = 2.0 ** -21 if prec == hip.PREC_F16 else 2.0 ** -19
+        assert bool(((hi.float() + lo.float() - y32).abs() <= torch.maximum(rel * y32.abs(), torch.full_like(y32, 2.0 ** -24))).all())
+        hi2 = torch.zeros_like(hi); lo2 = torch.zeros_like(lo)
+        hip.layernorm(x, g1, b1, prec=prec, out_hi=hi2, out_lo=lo2)
+        assert torch.equal(hi2, hi) and torch.equal(lo2, lo)
+        with pytest.raises(hip.GavaError):
+            hip.layernorm(x, g1, b1, prec=prec, out_hi=hi2)
+
+
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("M,D", [(45000, 768), (300, 768), (20000, 1024)])
 def test_ping_pong_loop_in_the_forward_forms_is_bit_identical(prec, M, D):
     """The forms the inference driver launches on the ping-pong loop - residual producers with the 16-bit copy and the

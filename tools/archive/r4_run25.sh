@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r4hl
+timeout -k 10 500 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "residual_stream_as_16_bit_pair or layernorm_and_join_rows" > gpurun_out/r4hl/ops.log 2>&1; echo "ops rc $?"; tail -3 gpurun_out/r4hl/ops.log
+timeout -k 10 400 python -m pytest tests/test_gpu_forward.py -q -s -m gpu -k "residual_stream_as_16_bit_pair" > gpurun_out/r4hl/fwd.log 2>&1; echo "fwd rc $?"; grep "^\[" gpurun_out/r4hl/fwd.log; tail -3 gpurun_out/r4hl/fwd.log
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-train --no-accuracy > gpurun_out/r4hl/bench.json 2> gpurun_out/r4hl/bench.err; echo "bench rc $?"; tail -c 1500 gpurun_out/r4hl/bench.json

@@ -16,7 +16,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 S=$(find $O/prof_train -name "*kernel_stats.csv" | head -1); cp $S $O/train_step_c2_kernel_stats.csv; rm -rf $O/prof_train
 head -6 $O/train_step_c2_kernel_stats.csv | cut -c1-170
 cd $R
-for k in fc1part qkvpart outpart fc2part attn; do
+for k in fc1part qkvpart outpair fc2pair attn; do
   bash tools/pmc.sh ${TAG}_$k $k --iters 3 > $O/pmc_$k.txt 2>&1
   rm -rf $R/gpurun_out/pmc_${TAG}_$k
   echo "== $k"; grep -E "^void|^\(anon|FETCH_SIZE|WRITE_SIZE|TCC_HIT|TCC_MISS|MFMA_BUSY|GRBM" $O/pmc_$k.txt | cut -c1-120

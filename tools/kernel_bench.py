@@ -63,6 +63,16 @@ elif a.which in ("fc2part", "outpart"):      # producers with the row sums pre-r
     A, W, b, O = rn(R, K), rn(D, K, scale=K ** -0.5), rn(D, dtype=torch.float32), rn(R, D, dtype=torch.float32)
     x16, part = torch.empty(Rp, D, dtype=dt, device=d), torch.empty(Rp + 32, 4, 2, dtype=torch.float32, device=d)
     fn = lambda: hip.gemm(A, W, b, O, epilogue=hip.EPI_F32, prec=prec, resid=O, x16_out=x16, rowsum_out=part, rowsum_reduced=True); fl = 2.0 * R * K * D
+elif a.which in ("fc2pair", "outpair"):      # producers with the residual stream as a 16-bit pair (what the big-batch forward launches)
+    K = F if a.which == "fc2pair" else D
+    Rp = (R + 255) // 256 * 256
+    A, W, b = rn(R, K), rn(D, K, scale=K ** -0.5), rn(D, dtype=torch.float32)
+    X = rn(R, D, dtype=torch.float32)
+    hi = torch.zeros(Rp, D, dtype=dt, device=d); hi[:R] = X.to(dt)
+    lo = torch.zeros(Rp, D, dtype=torch.float16, device=d); lo[:R] = (X - hi[:R].float()).half()
+    part = torch.empty(Rp + 32, 4, 2, dtype=torch.float32, device=d)
+    fn = lambda: hip.gemm(A, W, b, None, epilogue=hip.EPI_F32, prec=prec, resid16=hi, resid_lo=lo, x16_out=hi, xlo_out=lo, rowsum_out=part,
+                          rowsum_reduced=True, M=R); fl = 2.0 * R * K * D
 elif a.which in ("fc1fold", "qkvfold"):      # consumers of the LayerNorm folding
     N = F if a.which == "fc1fold" else 3 * D
     Rp = (R + 255) // 256 * 256

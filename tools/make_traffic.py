@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """profiles/traffic.json from the PMC passes of tools/pmc.sh, one file per per-layer kernel in the form the forward launches
 it (run on the GPU box: `bash tools/pmc.sh r3_fc1part fc1part --iters 3 > gpurun_out/r3final/pmc_fc1part.txt`, likewise
-qkvpart / outpart / fc2part / attn): FETCH_SIZE / WRITE_SIZE per launch, corrected as /opt/skills/guides/MI355X_MICROARCH.md
+qkvpart / outpair / fc2pair / attn): FETCH_SIZE / WRITE_SIZE per launch, corrected as /opt/skills/guides/MI355X_MICROARCH.md
 prescribes for gfx950 (FETCH_SIZE counts 128-B requests at 64 B -> x2; WRITE_SIZE exact for 16-B/lane stores), together
 with the sha256 of the kernel sources the passes were measured on - bench.py refuses to report traffic measured on other
 sources.
 
-    python tools/make_traffic.py DIR [profiles/traffic.json]      # DIR holds pmc_{fc1part,qkvpart,outpart,fc2part,attn}.txt
+    python tools/make_traffic.py DIR [profiles/traffic.json]      # DIR holds pmc_{fc1part,qkvpart,outpair,fc2pair,attn}.txt
 """
 import json
 import os
@@ -21,8 +21,9 @@ M, D, F = 100864, 768, 3072
 CASES = {
     "fc1": ("fc1part", "gemm256_kernel<PrecF16, 1, false, false, true, false, 0, false>", M * D * 2 + F * D * 2 + M * F * 2 + M * 8),
     "qkv": ("qkvpart", "gemm256_kernel<PrecF16, 0, false, false, true, false, 0, false>", M * D * 2 + 3 * D * D * 2 + M * 3 * D * 2 + M * 8),
-    "out": ("outpart", "gemm256_kernel<PrecF16, 2, true, false, false, true>", M * D * 2 + M * D * 10 + D * D * 2 + M * (D // 64) * 8),
-    "fc2": ("fc2part", "gemm256_kernel<PrecF16, 2, true, false, false, true>", M * F * 2 + M * D * 10 + D * F * 2 + M * (D // 64) * 8),
+    # (the big-batch forward keeps the residual stream as a 16-bit pair: 8 bytes per element through the producers' epilogue)
+    "out": ("outpair", "gemm256_kernel<PrecF16, 2, true, false, false, true>", M * D * 2 + M * D * 8 + D * D * 2 + M * (D // 64) * 8),
+    "fc2": ("fc2pair", "gemm256_kernel<PrecF16, 2, true, false, false, true>", M * F * 2 + M * D * 8 + D * F * 2 + M * (D // 64) * 8),
     "attn": ("attn", "attention_persist_kernel<PrecF16, 14, 13>", M * 3 * D * 2 + M * D * 2),
 }
 
