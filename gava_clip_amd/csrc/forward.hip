@@ -266,6 +266,16 @@ extern "C" int gava_vision_pair_stream(const gava_vision_model* m) {
 #endif
 extern "C" int gava_abi_version(void) { return (int)(GAVA_ABI_HASH); }
 
+extern "C" int gava_struct_sizes(size_t* out, int cap) {
+  const size_t v[] = {sizeof(gava_gemm_args), sizeof(gava_layernorm_args), sizeof(gava_attention_args), sizeof(gava_attention_f32_args),
+                      sizeof(gava_clip_desc), sizeof(gava_vision_layer), sizeof(gava_vision_layer8), sizeof(gava_vision_model),
+                      sizeof(gava_text_layer), sizeof(gava_text_model), sizeof(gava_layernorm_bwd_args), sizeof(gava_attention_bwd_args),
+                      sizeof(gava_vision_saved), sizeof(gava_preprocess_args), sizeof(gava_patchify_args)};
+  const int n = (int)(sizeof(v) / sizeof(v[0]));
+  for (int i = 0; out && i < n && i < cap; ++i) out[i] = v[i];
+  return n;
+}
+
 extern "C" int gava_probe_fc1_enable(int on) {
   Fc1Probe& g_probe = device_ctx().probe;
   if (on < 0 || on > GAVA_PROBE_ATTN) return GAVA_EINVAL;

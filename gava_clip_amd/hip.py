@@ -23,7 +23,7 @@ EXPORTS = ["gava_abi_version", "gava_gemm", "gava_layernorm", "gava_attention",
            "gava_preprocess_clip", "gava_layernorm_backward", "gava_qgelu_backward", "gava_attention_backward",
            "gava_text_forward_train", "gava_vision_forward_train", "gava_attention_backward_workspace_bytes", "gava_vision_forward_keep", "gava_row_stats",
            "gava_probe_fc1_enable", "gava_probe_fc1_read", "gava_clip_geometry", "gava_patchify", "gava_attention_f32",
-           "gava_gemm_aligned_walk", "gava_vision_pair_stream"]
+           "gava_gemm_aligned_walk", "gava_vision_pair_stream", "gava_struct_sizes"]
 
 _vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p  # all device pointers travel as void*
 
@@ -228,6 +228,18 @@ def load():
     lib.gava_vision_forward_train.restype = C.c_int
     lib.gava_text_forward_train.argtypes = [C.POINTER(TextModel), _ip, _fp, _ip, _fp, _fp, _vp, C.c_size_t, _vp]
     lib.gava_text_forward_train.restype = C.c_int
+    lib.gava_vision_pair_stream.argtypes, lib.gava_vision_pair_stream.restype = [C.POINTER(VisionModel)], C.c_int
+    # the header the library was compiled from against the mirrors above (gava_abi_version ties library and header)
+    mirrors = [GemmArgs, LayerNormArgs, AttentionArgs, AttentionF32Args, ClipDesc, VisionLayer, VisionLayer8, VisionModel, TextLayer,
+               TextModel, LayerNormBwdArgs, AttentionBwdArgs, VisionSaved, PreprocessArgs, PatchifyArgs]
+    sizes = (C.c_size_t * len(mirrors))()
+    lib.gava_struct_sizes.argtypes, lib.gava_struct_sizes.restype = [C.POINTER(C.c_size_t), C.c_int], C.c_int
+    if lib.gava_struct_sizes(sizes, len(mirrors)) != len(mirrors):
+        raise GavaError("libgava_hip.so and gava_clip_amd/hip.py disagree on the number of ABI structs")
+    for cls, sz in zip(mirrors, sizes):
+        if C.sizeof(cls) != sz:
+            raise GavaError(f"ctypes mirror {cls.__name__} is {C.sizeof(cls)} bytes, the library's struct {sz}: gava_clip_amd/hip.py is out of "
+                            f"step with include/gava_hip.h")
     _lib = lib
     return lib
 

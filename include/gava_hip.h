@@ -491,6 +491,13 @@ int gava_patchify(const gava_patchify_args* a, gava_stream_t stream);
 /* fp32 -> h16 conversion of a contiguous array (weight packing at load time). */
 int gava_convert_h16(const float* in, void* out, size_t n, int prec, gava_stream_t stream);
 
+/* sizeof of every ABI struct as the library was compiled, in the order gemm_args, layernorm_args, attention_args,
+ * attention_f32_args, clip_desc, vision_layer, vision_layer8, vision_model, text_layer, text_model, layernorm_bwd_args,
+ * attention_bwd_args, vision_saved, preprocess_args, patchify_args.  Writes min(cap, 15) entries, returns 15.  A binding
+ * compares them with its own mirrors at load time (gava_clip_amd/hip.py does): gava_abi_version ties the library to the
+ * header, this ties the header to the mirrors. */
+int gava_struct_sizes(size_t* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

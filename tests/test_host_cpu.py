@@ -65,6 +65,23 @@ def test_ctypes_structs_match_header_sizes():
         assert ctypes.sizeof(cls) == sizes[n], n
 
 
+def test_load_refuses_a_ctypes_mirror_that_is_out_of_step(monkeypatch):
+    """gava_struct_sizes: load() compares sizeof of every ABI struct as the library was compiled with the ctypes mirrors and
+    refuses a mismatch (the ABI hash ties library and header, this ties header and mirrors) - without a GPU."""
+    from gava_clip_amd import hip
+    hip.load()
+
+    class Short(ctypes.Structure):
+        _fields_ = hip.GemmArgs._fields_[:-1]
+    monkeypatch.setattr(hip, "GemmArgs", Short)
+    monkeypatch.setattr(hip, "_lib", None)
+    with pytest.raises(hip.GavaError, match="out of step"):
+        hip.load()
+    monkeypatch.undo()
+    hip._lib = None
+    hip.load()
+
+
 @pytest.mark.parametrize("cfg,cls_file,n_cls", [(TINY, CLASSES_3, 3), (VIT_B16_T8, CLASSES_400, 400)])
 def test_state_dict_keys_match_reference(cfg, cls_file, n_cls):
     from gava_clip_amd import VitaCLIP
