@@ -669,6 +669,38 @@ class _HipHost:
         self.last["cls_rows"] = dbg
         return cls_x, summary
 
+    def _overlapping_stream(self, device):
+        """A new stream that really runs BESIDE the current one.  HIP multiplexes streams onto a few hardware queues in creation
+        order; a stream that shares the current stream's queue is served in order with it, and the text tower then runs serially
+        in front of the vision tower (23.0 instead of 20.7 ms per c2 forward, profiles/r04_text_cost.txt) - which queue a new stream
+        gets depends on how many the process has created before (data loaders, DDP).  So the candidate is tried once: a ~1 ms spin
+        on the current stream, a one-element fill on the candidate; a candidate whose fill is not done long before the spin ends is
+        set aside (kept alive, so that the next one gets another queue) and the next is tried, four at most."""
+        if torch.cuda.is_current_stream_capturing():
+            return torch.cuda.Stream(device=device)
+        main = torch.cuda.current_stream(device)
+        tried = []
+        with torch.cuda.device(device):
+            for _ in range(4):
+                cand = torch.cuda.Stream(device=device)
+                tried.append(cand)
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                with torch.cuda.stream(cand):
+                    torch.zeros(1, device=device)                # first use of the stream (its queue is set up here), untimed
+                torch.cuda.synchronize(device)
+                e0.record(main)
+                torch.cuda._sleep(2_000_000)
+                e1.record(main)
+                with torch.cuda.stream(cand):
+                    torch.zeros(1, device=device)
+                    e2.record(cand)
+                torch.cuda.synchronize(device)
+                if e2.elapsed_time(e1) > 0.3 * e0.elapsed_time(e1):     # the fill was done while the spin still had most of its time to go
+                    break
+        self._queue_sharing_streams = tried[:-1]
+        self.last["text_stream_candidates"] = len(tried)
+        return tried[-1]
+
     def _text_shard(self, n):
         """(lo, hi, rows per rank, world) when the prompts are sharded over the ranks, else None (SURVEY.md 8f row 2:
         every rank would otherwise run the whole text tower redundantly - 2.4 TF per forward at 400 classes)."""
@@ -1047,7 +1079,7 @@ class VitaCLIP(nn.Module, _HipHost):
                     # (and inserts the cross-stream waits), so the text tower overlaps the vision tower both ways
                     main = torch.cuda.current_stream(x.device)
                     if self._text_stream is None or self._text_stream.device != x.device:
-                        self._text_stream = torch.cuda.Stream(device=x.device)
+                        self._text_stream = self._overlapping_stream(x.device)
                     text_stream = self._text_stream
                     text_stream.wait_stream(main)
                     with torch.cuda.stream(text_stream):
@@ -1062,7 +1094,7 @@ class VitaCLIP(nn.Module, _HipHost):
                 main = torch.cuda.current_stream(x.device)
                 if self.text_on_side_stream:
                     if self._text_stream is None or self._text_stream.device != x.device:
-                        self._text_stream = torch.cuda.Stream(device=x.device)
+                        self._text_stream = self._overlapping_stream(x.device)
                     text_stream = self._text_stream
                     text_stream.wait_stream(main)
                     with torch.cuda.stream(text_stream):

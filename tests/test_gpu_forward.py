@@ -367,6 +367,25 @@ def test_forward_is_hipgraph_capturable_and_side_streams_join():
     assert not torch.equal(got, ref)
 
 
+def test_text_stream_really_runs_beside_the_main_stream():
+    """HIP multiplexes streams onto a few hardware queues in creation order; a text stream that shares the main stream's queue
+    serialises the two towers.  model._overlapping_stream tries candidates: whatever number of streams the process created before,
+    the stream it returns finishes a one-element fill long before a 1 ms spin on the main stream ends."""
+    m, _ = build(TINY)
+    held = []
+    for pre in range(6):
+        held.append(torch.cuda.Stream())              # one more stream created by "the host program" each time
+        s = m._overlapping_stream(torch.device("cuda", torch.cuda.current_device()))
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        torch.cuda.synchronize()
+        e0.record(); torch.cuda._sleep(2_000_000); e1.record()
+        with torch.cuda.stream(s):
+            torch.zeros(1, device="cuda"); e2.record(s)
+        torch.cuda.synchronize()
+        assert e2.elapsed_time(e1) > 0.3 * e0.elapsed_time(e1), (pre, m.last["text_stream_candidates"])
+        assert 1 <= m.last["text_stream_candidates"] <= 4
+
+
 def test_text_rows_behind_the_last_eot_are_dead_work():
     """The text tower runs on the first L_eff = last EOT position + 1 rows of every prompt (causal attention: the EOT
     row cannot see later rows); the reference pads all prompts to 77.  Same logits and text features as the full run."""

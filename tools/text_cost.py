@@ -54,8 +54,12 @@ for r in range(a.rounds):
             if not kk.startswith("_"):
                 setattr(m, kk, v)
         pr = kw.get("_prio")
-        m._text_stream = torch.cuda.Stream(device=x.device, priority=(least if pr == "low" else greatest)) if pr else torch.cuda.Stream(device=x.device)
+        # default modes: the model picks its own text stream again (model._overlapping_stream tries candidates until one runs beside
+        # the main stream); priority modes: a raw new stream, as before
+        m._text_stream = torch.cuda.Stream(device=x.device, priority=(least if pr == "low" else greatest)) if pr else None
         m._text_cache = None
         res[k].append(timed())
+        if not pr and kw["text_on_side_stream"] and not kw["cache_text_features"]:
+            print(f"round {r}: text stream candidates tried {m.last.get('text_stream_candidates')}")
 for k, v in res.items():
     print(f"{k:26s} median {sorted(v)[len(v) // 2]:.3f} ms  ({' '.join('%.3f' % t for t in v)})")
