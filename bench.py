@@ -248,7 +248,7 @@ def kernel_table(cfg, B, prec, fold=False, pair=False):
     # k-loop, residual stream as a 16-bit pair;
     # the walk is the launcher's own decision for this shape on this device (gava_gemm_aligned_walk), not assumed
     walk = "true" if hip.load().gava_gemm_aligned_walk(R, D, 0) else "false"
-    pp_env = os.environ.get("GAVA_PP", "2")      # the launcher's switch: 2 (default) = ping-pong k-loop for the fp32-output GEMMs
+    pp_env = os.environ.get("GAVA_PP", "1")      # the launcher's switch: 1 (default) = ping-pong k-loop wherever an instantiation exists, 2 = fp32-output GEMMs only
     pp, ppc = ("true" if pp_env in ("1", "2") else "false"), ("true" if pp_env == "1" else "false")
     hl = "true" if (fold and pair) else "false"
     if fold and pair:

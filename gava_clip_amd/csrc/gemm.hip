@@ -45,6 +45,12 @@ namespace {
 #define ABLATE 0
 #endif
 constexpr int BK = 64;
+// PP2 (default): the ping-pong loop in two 32-MFMA phases per k-tile (half the barriers) instead of four 16-MFMA ones - plain GEMMs
+// 8192^3 1368 -> 1445 TF/s, the fc1 shape 1022 -> 1076 (vendor 1065), K = 3072 1151 -> 1221 (vendor 1067); c2 forward -1.1 %, c5 -3.1 %
+// (profiles/r04_pingpong.txt).  -DGAVA_PP2=0: the four-phase loop (A/B builds)
+#ifndef GAVA_PP2
+#define GAVA_PP2 1
+#endif
 // s_waitcnt immediate for "vmcnt(n) only" on gfx9/CDNA: vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14
 
 struct GemmParams {
@@ -472,6 +478,7 @@ template <class P, int EPI, bool RES, bool SPLIT, bool FOLD = false, bool ALIGN 
 __global__ __launch_bounds__(512, 2)
 void gemm256_kernel(const GemmParams p) {
   static_assert(!(PP && L8 == 2), "the ping-pong loop has no 8-bit stages");
+  constexpr bool PP2 = GAVA_PP2 && PP;
   static_assert(!HL || (PP && RES && EPI == GAVA_EPI_F32 && !L8 && !FOLD && !SPLIT), "HL: the residual producers on the ping-pong loop");
   constexpr int BM = 256, BN = 256, NW = 8;
   constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;   // 32 KiB, 64 KiB
@@ -813,7 +820,9 @@ void gemm256_kernel(const GemmParams p) {
   }
   if (PP) {
     // half-tiles 0, 1 (and the residual tile, older) have landed; the barrier publishes them; then group 1 falls one barrier behind
-    if (!CAN_FOLD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // (PP2: its first phase reads half-tiles 0, 1 and 2)
+    if (PP2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (!CAN_FOLD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     resid_up();
     if (wr == 1) __builtin_amdgcn_s_barrier();
@@ -891,6 +900,7 @@ void gemm256_kernel(const GemmParams p) {
       // vmcnt(n) for the handful of counts the schedule uses (the immediate must be a literal)
       auto wait_vm = [&](int n) {
         if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (n == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
         else if (n == 8 + NSTORE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NSTORE <= 63 ? 8 + NSTORE : 0) : "memory");
@@ -986,9 +996,87 @@ void gemm256_kernel(const GemmParams p) {
           __builtin_amdgcn_s_barrier();
         }
       };
+      // PP2: a k-tile in TWO phases of 32 MFMAs.  Phase 0 = the quadrants (0,0) (0,1) - it reads A half 0 and both W halves - and stages
+      // the half-tiles 2, 3 of the next k-tile (other buffer); phase 1 = (1,1) (1,0) - it reads A half 1 - and stages the half-tiles 0, 1 of
+      // the k-tile after next (this buffer: last read a phase ago, the partner group is one barrier behind and past its reads).  Four
+      // LDS-DMA pieces per wave and phase; the wait at the end of a load section retires what the NEXT phase reads: phase 0 leaves the
+      // two younger phases' pieces in flight (8), phase 1 - whose successor reads three half-tiles - all but the youngest half-tile and
+      // its own (6).  Same k order per accumulator as the four-phase loop: bit-identical results.
+      auto pp2_ktile = [&](int kt, auto Bc) {
+        constexpr int B = decltype(Bc)::value;
+        const char* buf = smem + B * STAGE;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          if (ph == 0) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              w0f[jj][0] = *reinterpret_cast<const s16x8_t*>(buf + 1 * HALF + pp_w + jj * PP_WJ + pp_k0);
+              w0f[jj][1] = *reinterpret_cast<const s16x8_t*>(buf + 1 * HALF + pp_w + jj * PP_WJ + pp_k1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              af[i][0] = *reinterpret_cast<const s16x8_t*>(buf + 0 * HALF + pp_a + i * 2048 + pp_k0);
+              af[i][1] = *reinterpret_cast<const s16x8_t*>(buf + 0 * HALF + pp_a + i * 2048 + pp_k1);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              w1f[jj][0] = *reinterpret_cast<const s16x8_t*>(buf + 2 * HALF + pp_w + jj * PP_WJ + pp_k0);
+              w1f[jj][1] = *reinterpret_cast<const s16x8_t*>(buf + 2 * HALF + pp_w + jj * PP_WJ + pp_k1);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              af[i][0] = *reinterpret_cast<const s16x8_t*>(buf + 3 * HALF + pp_a + i * 2048 + pp_k0);
+              af[i][1] = *reinterpret_cast<const s16x8_t*>(buf + 3 * HALF + pp_a + i * 2048 + pp_k1);
+            }
+          }
+          // two k-tiles before the end of the tile the staging crosses into the next tile: its coordinates at phase 0, its sources at
+          // phase 1 (before that phase stages the next tile's first half-tiles)
+          if (kt == nk - 2 && has_next) {
+            if (ph == 0) {
+              tile_coords(j + 1, m0n, n0n);
+              if (CAN_FOLD) fold_fetch(j + 1, m0n, n0n);      // 3 more LDS-DMA loads, older than this phase's pieces
+            } else set_src(m0n, n0n);
+          }
+          const int ktt = kt + (ph == 0 ? 1 : 2);
+          const bool more = ktt < nk || has_next;
+          if (more) {
+            stage_half(ktt < nk ? ktt : ktt - nk, ph == 0 ? 2 : 0, ph == 0 ? (B ^ 1) : B);
+            stage_half(ktt < nk ? ktt : ktt - nk, ph == 0 ? 3 : 1, ph == 0 ? (B ^ 1) : B);
+          }
+          if (!more) wait_vm(0);
+          else if (kt == 0 && j > 0 && ph == 0) wait_vm(counted == 0 ? 0 : (counted == 2 ? 8 + 2 * NSTORE : 8 + NSTORE));
+          else if (CAN_FOLD && kt == nk - 2 && has_next && ph == 0) wait_vm(11);      // + the fold block (retired by phase 1's wait)
+          else wait_vm(ph == 0 ? 8 : 6);
+          __builtin_amdgcn_s_barrier();
+          if (ROWSUM && p.rowsum_reduced && kt == 0 && ph == 0 && j > 0) flush_rowsum(m0p, n0p);
+          if (HL && B == 0 && ph == 0 && kt == 0 && j > 0) resid_up();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj) {
+                acc[ph * 4 + i][jj] = P::mfma(w0f[jj][kk], af[i][kk], acc[ph * 4 + i][jj]);
+                acc[ph * 4 + i][2 + jj] = P::mfma(w1f[jj][kk], af[i][kk], acc[ph * 4 + i][2 + jj]);
+              }
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (CAN_FOLD && p.fpart && kt == nk - 1 && ph == 0 && has_next) fold_reduce(j + 1);   // fetched a k-tile ago, landed by now
+          __builtin_amdgcn_s_barrier();
+        }
+      };
       for (int kt = 0; kt < nk; kt += 2) {      // K % 128 == 0: the two k-tile buffers alternate statically
-        pp_ktile(kt, std::integral_constant<int, 0>{});
-        pp_ktile(kt + 1, std::integral_constant<int, 1>{});
+        if (PP2) {
+          pp2_ktile(kt, std::integral_constant<int, 0>{});
+          pp2_ktile(kt + 1, std::integral_constant<int, 1>{});
+        } else {
+          pp_ktile(kt, std::integral_constant<int, 0>{});
+          pp_ktile(kt + 1, std::integral_constant<int, 1>{});
+        }
       }
       // The epilogues of the two groups must run side by side, not one after the other (a group that is a barrier ahead would
       // wait at its next barrier for the other group's whole epilogue, and vice versa): group 0 waits here for group 1's last
@@ -1374,11 +1462,12 @@ bool patch_on_256() {
   return v != 0;
 }
 
-// where AUTO takes the ping-pong loop: GAVA_PP = 0 nowhere, 1 wherever an instantiation exists, 2 (default) the fp32-output
-// GEMMs - the residual producers out_proj / fc2 and the deep-K dgrad GEMMs of the backward (measured faster there: K = 3072 by
-// 4-7 %, out_proj by 3 %; the K = 768 LayerNorm-folded consumers are 3-4 % slower on it: profiles/r04_pingpong.txt)
+// where AUTO takes the ping-pong loop: GAVA_PP = 0 nowhere, 1 (default) wherever an instantiation exists, 2 the fp32-output GEMMs
+// only (the residual producers out_proj / fc2 and the deep-K dgrad GEMMs of the backward).  With the four-phase loop the K = 768
+// LayerNorm-folded consumers were 3-4 % slower on it and 2 was the default; on the two-phase loop they are level stand-alone and
+// the forward gains with them (c2 -0.5 %, c5 -1.5 % on top of the producers': profiles/r04_pingpong.txt)
 int pp_mode() {
-  static const int v = getenv("GAVA_PP") ? atoi(getenv("GAVA_PP")) : 2;
+  static const int v = getenv("GAVA_PP") ? atoi(getenv("GAVA_PP")) : 1;
   return v;
 }
 

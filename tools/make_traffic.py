@@ -19,8 +19,8 @@ sys.path.insert(0, REPO)
 # bench.py key -> (pmc file tag, substring of the kernel name rocprofv3 prints, algorithmic bytes per launch at c2)
 M, D, F = 100864, 768, 3072
 CASES = {
-    "fc1": ("fc1part", "gemm256_kernel<PrecF16, 1, false, false, true, false, 0, false>", M * D * 2 + F * D * 2 + M * F * 2 + M * 8),
-    "qkv": ("qkvpart", "gemm256_kernel<PrecF16, 0, false, false, true, false, 0, false>", M * D * 2 + 3 * D * D * 2 + M * 3 * D * 2 + M * 8),
+    "fc1": ("fc1part", "gemm256_kernel<PrecF16, 1, false, false, true, false, 0, true, false>", M * D * 2 + F * D * 2 + M * F * 2 + M * 8),
+    "qkv": ("qkvpart", "gemm256_kernel<PrecF16, 0, false, false, true, false, 0, true, false>", M * D * 2 + 3 * D * D * 2 + M * 3 * D * 2 + M * 8),
     # (the big-batch forward keeps the residual stream as a 16-bit pair: 8 bytes per element through the producers' epilogue)
     "out": ("outpair", "gemm256_kernel<PrecF16, 2, true, false, false, true>", M * D * 2 + M * D * 8 + D * D * 2 + M * (D // 64) * 8),
     "fc2": ("fc2pair", "gemm256_kernel<PrecF16, 2, true, false, false, true>", M * F * 2 + M * D * 8 + D * F * 2 + M * (D // 64) * 8),
