@@ -577,27 +577,21 @@ void gemm256_kernel(const GemmParams p) {
     int ln = lane;
     if (FOLD || GAVA_V3_RECOMPUTE_SRC) asm volatile("" : "+v"(ln));
     if (PP) {
-      // src[2 s + i]: piece (wave + 8 i) of half-tile slot s (0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1); lr = the
-      // piece's row in the half-tile.  A half mi holds tile rows (lr >> 6) * 128 + mi * 64 + (lr & 63); W half ni holds, per wave
-      // column block (lr >> 5), the 32 W rows whose fragments quadrant ni multiplies: natural order ni * 32 + (lr & 31), or - the
-      // 16-bit outputs' permuted order, 16 consecutive columns per lane - 16 * ((lr >> 3) & 3) + 8 * ni + (lr & 7).
-#pragma unroll
-      for (int sl = 0; sl < 4; ++sl)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int lr = (wave + 8 * i) * 8 + (ln >> 3);
-          if (sl == 0 || sl == 3) {
-            const int mi = sl == 3;
-            int gm = m0 + (lr >> 6) * 128 + mi * 64 + (lr & 63);
-            gm = gm < p.M ? gm : p.M - 1;
-            src[2 * sl + i] = ((unsigned)gm * (unsigned)p.lda + (((ln & 7) ^ ((lr >> 1) & 7)) * 8)) * 2u;
-          } else {
-            const int ni = sl - 1;
-            const int wrow = (NAT || HL) ? (lr >> 5) * 64 + ni * 32 + (lr & 31) : (lr >> 5) * 64 + 16 * ((lr >> 3) & 3) + 8 * ni + (lr & 7);
-            const int sw = NAT ? ((lr >> 1) & 7) : (((lr >> 1) & 1) | (((lr >> 3) & 3) << 1));
-            src[2 * sl + i] = ((unsigned)(n0 + wrow) * (unsigned)p.ldw + (((ln & 7) ^ sw) * 8)) * 2u;
-          }
-        }
+      // Half-tile slot s (0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1), piece (wave + 8 i), i = 0 / 1; lr = the piece's row in
+      // the half-tile.  A half mi holds tile rows (lr >> 6) * 128 + mi * 64 + (lr & 63); W half ni holds, per wave column block (lr >> 5),
+      // the 32 W rows whose fragments quadrant ni multiplies: natural order ni * 32 + (lr & 31), or - the 16-bit outputs' permuted order,
+      // 16 consecutive columns per lane - 16 * ((lr >> 3) & 3) + 8 * ni + (lr & 7).  The eight lane offsets differ by UNIFORM amounts
+      // (i adds 128 rows, mi 64, ni 32 or 8; the swizzle terms do not change), so three registers stand for them - src[0] = A piece
+      // (slot 0, i 0), src[1] = the lane's offset in the last valid A row (rows past M read that row: a v_min at the use instead of a
+      // clamp per entry), src[2] = W piece (slot 1, i 0) - and stage_half adds the uniform part.  (Eight registers before: the LayerNorm-folded
+      // kernels on the two-phase loop then spilled 20 B/lane, and every reload of a spill waits on vmcnt(0), i.e. on the operand prefetch.)
+      const int lr = wave * 8 + (ln >> 3);
+      const unsigned chunk_a = (unsigned)(((ln & 7) ^ ((lr >> 1) & 7)) * 8);
+      src[0] = ((unsigned)(m0 + (lr & 63)) * (unsigned)p.lda + chunk_a) * 2u;
+      src[1] = ((unsigned)(p.M - 1) * (unsigned)p.lda + chunk_a) * 2u;
+      const int wrow = (NAT || HL) ? (lr >> 5) * 64 + (lr & 31) : (lr >> 5) * 64 + 16 * ((lr >> 3) & 3) + (lr & 7);
+      const int sw = NAT ? ((lr >> 1) & 7) : (((lr >> 1) & 1) | (((lr >> 3) & 3) << 1));
+      src[2] = ((unsigned)(n0 + wrow) * (unsigned)p.ldw + (unsigned)(((ln & 7) ^ sw) * 8)) * 2u;
       return;
     }
 #pragma unroll
@@ -676,9 +670,19 @@ void gemm256_kernel(const GemmParams p) {
     const bool is_a = sl == 0 || sl == 3;
     if (is_a && kt >= p.nka) kt -= p.nka;           // w_lo = 1: the second half of the k-loop re-reads A
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(reinterpret_cast<const char*>(is_a ? p.A : p.W) + (size_t)(src[2 * sl + i] + (unsigned)(kt * BK * 2))),
+    for (int i = 0; i < 2; ++i) {
+      unsigned off;
+      if (is_a) {
+        const unsigned rows = (unsigned)(i * 128 + (sl == 3 ? 64 : 0));
+        off = src[0] + rows * (unsigned)p.lda * 2u;
+        off = off < src[1] ? off : src[1];          // rows past M: the last valid row (their results are never stored)
+      } else {
+        const unsigned rows = (unsigned)(i * 128 + (sl == 2 ? ((NAT || HL) ? 32 : 8) : 0));
+        off = src[2] + rows * (unsigned)p.ldw * 2u;
+      }
+      __builtin_amdgcn_global_load_lds(GLB_PTR(reinterpret_cast<const char*>(is_a ? p.A : p.W) + (size_t)(off + (unsigned)(kt * BK * 2))),
                                        LDS_PTR(void, smem + b * STAGE + sl * HALF + (wave + 8 * i) * 1024), 16, 0, 0);
+    }
   };
   const int pp_a = (wr * 64 + fr) * 128, pp_w = (NAT ? (wc * 32 + fr) : (wc * 32 + 8 * (fr >> 2) + (fr & 3))) * 128;
   const int pp_k0 = (fg ^ (fr >> 1)) << 4, pp_k1 = ((4 + fg) ^ (fr >> 1)) << 4;
@@ -1190,10 +1194,16 @@ void gemm256_kernel(const GemmParams p) {
 #endif
     // ---- epilogue of tile j: lane holds out[m][n .. n+15], m = m0+wr*128+i*16+fr,
     //      n = n0 + wc*64 + 16*fg + 4*jj + r
-    const int nb0 = n0 + wc * 64 + (HL ? 8 : CF) * fg;
+    // (PP + fold: the lane-derived constants of the epilogue are derived HERE from a lane id the compiler cannot see through - kept live
+    // across the k-loop they were spilled (16 B/lane), and a spill reload is a scratch load: its s_waitcnt vmcnt(0) waited for the next
+    // tile's whole operand prefetch at the top of every epilogue and for this tile's stores at its end)
+    int lane_e = lane;
+    if (PP && FOLD) asm volatile("" : "+v"(lane_e));
+    const int fr_e = (PP && FOLD) ? (lane_e & 15) : fr, fg_e = (PP && FOLD) ? (lane_e >> 4) : fg;
+    const int nb0 = n0 + wc * 64 + (HL ? 8 : CF) * fg_e;
     float4 bj[4];
     if (CAN_FOLD) {   // t_n from this tile's fold block (LDS, by hand: see fold_init)
-      unsigned a_t = (lane >> 4) * 64u;
+      unsigned a_t = (lane_e >> 4) * 64u;
       asm volatile("" : "+v"(a_t));
       a_t += (unsigned)(size_t)LDS_PTR(char, smem) + 2 * STAGE + (j & 1) * FOLD_BYTES + wave * FOLD_WAVE;
       f32x4_t tj[4];
@@ -1219,7 +1229,7 @@ void gemm256_kernel(const GemmParams p) {
     // folded LayerNorm: out = rstd_m * acc + t_n (acc already holds x.W' - mean_m * s_n; t_n came in as the bias)
     // rstd of row i+1 is fetched (LDS, by hand: see fold_init) while row i is processed: two registers, not eight
     float r_cur = 0.f, r_next = 0.f;
-    unsigned a_r = (lane & 15) * 8u + 4u;
+    unsigned a_r = (lane_e & 15) * 8u + 4u;
     if (CAN_FOLD) {
       asm volatile("" : "+v"(a_r));
       a_r += pairs_base(j);
@@ -1227,7 +1237,7 @@ void gemm256_kernel(const GemmParams p) {
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wr * 128 + i * 16 + fr;
+      const int m = m0 + wr * 128 + i * 16 + fr_e;
       if (CAN_FOLD && i < 7) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r_next) : "v"(a_r), "n"((i + 1) * 128));
       if (m < p.M && !(ABLATE & 4)) {
         long orow = m;
@@ -1908,19 +1918,19 @@ template <class P>
 int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   static const int variant = getenv("GAVA_GEMM_VARIANT") ? atoi(getenv("GAVA_GEMM_VARIANT")) : 0;
   if (gp.r16) {   // the 16-bit residual pair: the persistent 256^2 kernel's ping-pong loop only; never fall back silently
-    const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
+    const bool fits = (unsigned long long)(gp.M + 256) * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
     if ((gp.kernel != GAVA_KERNEL_AUTO && gp.kernel != GAVA_KERNEL_PP) || gp.N % 256 || !fits || gp.frames || gp.clips) return GAVA_EINVAL;
     return launch_256<P, 3>(gp, epi, s);
   }
   if (gp.w_lo == 2 || gp.out8 || gp.x8) {   // only the persistent 256^2 kernel implements these; never fall back silently
-    const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
+    const bool fits = (unsigned long long)(gp.M + 256) * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
     if (gp.kernel == GAVA_KERNEL_PAIR || gp.N % 256 || !fits || gp.frames || gp.clips) return GAVA_EINVAL;
     return launch_256<P, 3>(gp, epi, s);
   }
   // fp32-output GEMMs with the heavy epilogue (residual stream, folding producers): the two-workgroups-per-CU kernel can
   // be named explicitly (gava_gemm_args.kernel)
   {
-    const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
+    const bool fits = (unsigned long long)(gp.M + 256) * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
     const long tiles128 = (long)((gp.M + 127) / 128) * (gp.N / 256);
     const bool can_pair = !gp.w_lo && epi == GAVA_EPI_F32 && gp.N % 256 == 0 && gp.N <= 1024 && gp.K % 128 == 0 && fits && !gp.frames &&
                           !gp.clips && (gp.rowsum_reduced || !gp.x16);
@@ -1936,7 +1946,7 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
     (void)tiles128;
   }
   if (gp.rowsum_reduced || gp.fpart) {   // only the persistent kernels implement these; never fall back silently
-    const bool fits = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
+    const bool fits = (unsigned long long)(gp.M + 256) * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
     return (gp.N % 256 == 0 && fits && !gp.frames && !gp.clips) ? launch_256<P, 3>(gp, epi, s) : GAVA_EINVAL;
   }
   // small-M problems (prompt path, text tower at few classes): 128x128 tiles fill more CUs;
@@ -1958,7 +1968,7 @@ int launch_prec(const GemmParams& gp, int epi, hipStream_t s) {
   // fc1 0.55 vs 0.78 ms) and, since the static wave priority, for the deep-K N = 768 GEMM (fc2 0.59 vs
   // 0.62 ms); the shallow one (out, K = 768: 0.28 vs 0.26 ms) stays on the 128^2 kernel, whose many small
   // workgroups spread the fp32 residual traffic better over its short k-loop
-  const bool fits32 = (unsigned long long)gp.M * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
+  const bool fits32 = (unsigned long long)(gp.M + 256) * gp.lda < (1ull << 31) && (unsigned long long)gp.N * gp.ldw < (1ull << 31);
   const long tiles256 = (long)((gp.M + 255) / 256) * (gp.N / 256);
   // ... and, since the fp32-output kernels use the natural column order (64 contiguous bytes per row and instruction in
   // the residual loads and the stores), also for the shallow fp32 GEMM: out 0.251 vs 0.268 ms on the 128^2 kernel
@@ -1976,7 +1986,7 @@ namespace gava {
 bool gemm_takes_pair(int M, int N, int K, long lda, long ldw) {
   const char* e = getenv("GAVA_PAIR_STREAM");      // read per call: the tests switch it inside one process
   const bool on = !(e && e[0] == '0');
-  const bool fits = (unsigned long long)M * lda < (1ull << 31) && (unsigned long long)N * ldw < (1ull << 31);
+  const bool fits = (unsigned long long)(M + 256) * lda < (1ull << 31) && (unsigned long long)N * ldw < (1ull << 31);
   return on && M > 0 && N % 256 == 0 && N <= 1024 && K % 128 == 0 && K >= 256 && fits;
 }
 }  // namespace gava
