@@ -1194,12 +1194,13 @@ void gemm256_kernel(const GemmParams p) {
 #endif
     // ---- epilogue of tile j: lane holds out[m][n .. n+15], m = m0+wr*128+i*16+fr,
     //      n = n0 + wc*64 + 16*fg + 4*jj + r
-    // (PP + fold: the lane-derived constants of the epilogue are derived HERE from a lane id the compiler cannot see through - kept live
+    // (the ping-pong kernels near the register limit: the lane-derived constants of the epilogue are derived HERE from a lane id the compiler cannot see through - kept live
     // across the k-loop they were spilled (16 B/lane), and a spill reload is a scratch load: its s_waitcnt vmcnt(0) waited for the next
     // tile's whole operand prefetch at the top of every epilogue and for this tile's stores at its end)
     int lane_e = lane;
-    if (PP && FOLD) asm volatile("" : "+v"(lane_e));
-    const int fr_e = (PP && FOLD) ? (lane_e & 15) : fr, fg_e = (PP && FOLD) ? (lane_e >> 4) : fg;
+    constexpr bool LAUNDER = (PP && (FOLD || (ACC_RES && !HL))) || (L8 == 2 && FOLD);      // the instantiations that spilled without it
+    if (LAUNDER) asm volatile("" : "+v"(lane_e));
+    const int fr_e = LAUNDER ? (lane_e & 15) : fr, fg_e = LAUNDER ? (lane_e >> 4) : fg;
     const int nb0 = n0 + wc * 64 + (HL ? 8 : CF) * fg_e;
     float4 bj[4];
     if (CAN_FOLD) {   // t_n from this tile's fold block (LDS, by hand: see fold_init)
@@ -1367,15 +1368,15 @@ void gemm256_kernel(const GemmParams p) {
               char* xs = smem + 2 * STAGE + wave * XS_WAVE;
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj)
-                *reinterpret_cast<uint2*>(xs + fr * XS_PITCH + (((2 * jj + (fg >> 1)) ^ ((fr >> 1) & 7)) << 4) + (fg & 1) * 8) =
+                *reinterpret_cast<uint2*>(xs + fr_e * XS_PITCH + (((2 * jj + (fg_e >> 1)) ^ ((fr_e >> 1) & 7)) << 4) + (fg_e & 1) * 8) =
                     pack4<P>(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) { ps1 += v[e]; ps2 += v[e] * v[e]; }
             ps1 = sum_across_lane_groups(ps1); ps2 = sum_across_lane_groups(ps2);
             if (p.rowsum_reduced) {
-              if (fg == 0) *reinterpret_cast<float2*>(smem + PS_OFF + ((wr * 128 + i * 16 + fr) * 4 + wc) * 8) = make_float2(ps1, ps2);
-            } else if (fg == 0) p.rowsum[orow * (p.N / 64) + (n0 + wc * 64) / 64] = make_float2(ps1, ps2);
+              if (fg_e == 0) *reinterpret_cast<float2*>(smem + PS_OFF + ((wr * 128 + i * 16 + fr_e) * 4 + wc) * 8) = make_float2(ps1, ps2);
+            } else if (fg_e == 0) p.rowsum[orow * (p.N / 64) + (n0 + wc * 64) / 64] = make_float2(ps1, ps2);
           }
         }
       }
@@ -1384,10 +1385,10 @@ void gemm256_kernel(const GemmParams p) {
         const char* xs = smem + 2 * STAGE + wave * XS_WAVE;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int row = (lane >> 3) + 8 * h;
-          const uint4 d = *reinterpret_cast<const uint4*>(xs + row * XS_PITCH + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+          const int row = (lane_e >> 3) + 8 * h;
+          const uint4 d = *reinterpret_cast<const uint4*>(xs + row * XS_PITCH + (((lane_e & 7) ^ ((row >> 1) & 7)) << 4));
           const int mm = m0 + wr * 128 + i * 16 + row;
-          if (mm < p.M) *reinterpret_cast<uint4*>(p.x16 + (long)mm * p.ldx16 + n0 + wc * 64 + (lane & 7) * 8) = d;
+          if (mm < p.M) *reinterpret_cast<uint4*>(p.x16 + (long)mm * p.ldx16 + n0 + wc * 64 + (lane_e & 7) * 8) = d;
           if (L8 && p.x8 && mm < p.M) {   // bf8 copy of the same 8 values (fp16 operands only)
             const unsigned dw[4] = {d.x, d.y, d.z, d.w};
             unsigned r8[2];
