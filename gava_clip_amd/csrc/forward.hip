@@ -163,9 +163,11 @@ struct VisionWs {
 int patch_k(const gava_vision_model* m) { return (3 * m->P * m->P + 63) / 64 * 64; }
 
 // The A operand of the patch-embedding GEMM.
-//   fp32 clips (the reference's input, the benchmark's): IM2COL-FREE - the GEMM builds its A tiles in the k-loop straight from
-//   the NCTHW frames (two coalesced float4 loads per 8 k-values, converted and written to the LDS stage: gemm_kernel's
-//   patch_load / patch_write); no patch matrix exists.  0.352 ms vs 0.343 ms for the two-pass form at c2 (inside box noise).
+//   fp32 clips (the reference's input, the benchmark's), small batches: IM2COL-FREE - the GEMM builds its A tiles in the k-loop straight
+//   from the NCTHW frames (two coalesced float4 loads per 8 k-values, converted and written to the LDS stage: gemm_kernel's
+//   patch_load / patch_write); no patch matrix exists, one launch.  Big batches (enough 256 x 256 tiles for the persistent kernel,
+//   round 4): two passes - the GEMM then runs the ping-pong loop of the persistent kernel on the 16-bit patch matrix, which the
+//   in-loop loader (a VALU-built LDS tile per stage) cannot: c2 forward 20.06 -> 19.91 ms same box (profiles/r04_pingpong.txt).
 //   decoded uint8 videos (forward_frames): two passes - gava_patchify writes the 16-bit patch matrix once (0.46 ms: every
 //   element is a bilinear sample, 4 byte loads + the lerp), the GEMM stages it by LDS-DMA (0.26 ms).  Built inside the k-loop
 //   the same samples are recomputed for each of the three 256-column tiles and cannot hide behind 0.23 GF of MFMA work per
@@ -177,7 +179,9 @@ int patch_operand(const gava_vision_model* m, const float* x, void* scratch, int
   // the in-loop loader reads the frames with float4 loads: a clip tensor whose storage is not 16-byte aligned (a view at an odd
   // offset) or whose rows are not a multiple of 4 floats takes the two-pass form, which has no such requirement
   const bool aligned = m->clips != nullptr || ((((uintptr_t)x) & 15) == 0 && m->size % 4 == 0);
-  const bool direct = forced >= 0 ? (forced != 0 && aligned) : (m->clips == nullptr && m->P % 8 == 0 && aligned);
+  const long gp_ = m->size / m->P, rows = (long)m->B * m->T_in * gp_ * gp_;
+  const bool big = m->D % 256 == 0 && (rows + 255) / 256 * (m->D / 256) >= 512;      // gemm.hip's condition for the persistent kernel
+  const bool direct = forced >= 0 ? (forced != 0 && aligned) : (m->clips == nullptr && m->P % 8 == 0 && aligned && !big);
   a->lda = Kp; a->frame_size = m->size; a->patch = m->P;
   if (direct) {
     a->A = nullptr; a->frames = m->clips ? nullptr : x; a->clips = m->clips; a->clip_lut = m->clip_lut;

@@ -1466,10 +1466,10 @@ int aligned_walk_sm(int tiles_m, int tiles_n, int sn, int blocks, int avail) {
   return rounds_aligned <= rounds_plain ? a_sm : 0;
 }
 
-// round-4 A/B: the two-pass patch embedding's GEMM (A = the 16-bit patch matrix) on the persistent 256^2 kernel instead of the
-// 128^2 tile kernel; GAVA_PATCH_256=0 / 1
+// the two-pass patch embedding's GEMM (A = the 16-bit patch matrix) on the persistent 256^2 kernel (ping-pong loop) instead of the
+// 128^2 tile kernel when the batch gives it enough tiles; GAVA_PATCH_256=0: the 128^2 kernel (A/B)
 bool patch_on_256() {
-  static const int v = getenv("GAVA_PATCH_256") ? atoi(getenv("GAVA_PATCH_256")) : 0;
+  static const int v = getenv("GAVA_PATCH_256") ? atoi(getenv("GAVA_PATCH_256")) : 1;
   return v != 0;
 }
 
@@ -1580,6 +1580,8 @@ int launch_256(GemmParams gp, int epi, hipStream_t s) {
         hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, false, false, false, true, 0, true>), grid, block, 0, s, gp);
       else if (epi == GAVA_EPI_F32)
         hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32, false, false, false, false, 0, true>), grid, block, 0, s, gp);
+      else if (epi == GAVA_EPI_F32_PATCH && gp.A)     // the two-pass patch embedding's GEMM (A = the 16-bit patch matrix)
+        hipLaunchKernelGGL((gemm256_kernel<P, GAVA_EPI_F32_PATCH, false, false, false, false, 0, true>), grid, block, 0, s, gp);
       else
         done = false;
       if (done) { GAVA_CHECK_LAUNCH(); return GAVA_OK; }
