@@ -157,11 +157,14 @@ def test_attention_plain_and_causal(prec, batch, heads, L, causal):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B,T,G,n_main,heads", [(2, 4, 4, 17, 2), (2, 8, 8, 197, 12), (1, 16, 8, 197, 3),
-                                                (11, 8, 8, 197, 13), (32, 8, 4, 130, 6)])
+                                                (11, 8, 8, 197, 13), (32, 8, 4, 130, 6),
+                                                (1, 32, 8, 257, 2), (2, 32, 8, 257, 3), (1, 32, 8, 241, 2), (1, 16, 8, 225, 2)])
 def test_attention_with_side_rows(prec, B, T, G, n_main, heads):
-    """Vision layout: per-frame main tokens + [G global | T per-clip local | 1 per-frame summary].  The last two cases have
+    """Vision layout: per-frame main tokens + [G global | T per-clip local | 1 per-frame summary].  Cases 4 and 5 have
     enough (frame, head) problems (>= 4 per CU) for the persistent double-buffered kernel, with an uneven number of
-    problems per workgroup."""
+    problems per workgroup.  The 257-query cases are ViT-L/14's (298 keys, the 320-key class): 16 query tiles + the CLS query,
+    whose tile the four waves of a workgroup share by keys (parts met in LDS); 241 (16 tiles, no odd one) and 225 (15 tiles: the
+    odd tile stays a half-empty pair) run the same class without the shared tile."""
     d = dev()
     dt = hip.h16_dtype(prec)
     D, BT = heads * 64, B * T
