@@ -129,6 +129,26 @@ static __device__ __forceinline__ void quick_gelu2(float& a, float& b) {
   a = y.x; b = y.y;
 }
 
+// Eight values at a time, stage by stage (all multiplies, all exps, all adds, all reciprocals, all multiplies): in the pairwise form
+// hipcc ran the sixteen values of a row group through ONE pair of temporaries - multiply, exp, add, rcp, multiply, each waiting for
+// the one before, an s_nop after every step (264 per tile in the fc1 kernel).  Stage-wise the eight chains advance side by side.
+static __device__ __forceinline__ void quick_gelu8(float (&v)[16], int base) {
+  f32x2_t t[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) t[q] = (f32x2_t){v[base + 2 * q], v[base + 2 * q + 1]} * (f32x2_t){-2.4554669595930157f, -2.4554669595930157f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) t[q] = (f32x2_t){__builtin_amdgcn_exp2f(t[q].x), __builtin_amdgcn_exp2f(t[q].y)};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) t[q] = t[q] + (f32x2_t){1.0f, 1.0f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) t[q] = (f32x2_t){__builtin_amdgcn_rcpf(t[q].x), __builtin_amdgcn_rcpf(t[q].y)};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2_t y = (f32x2_t){v[base + 2 * q], v[base + 2 * q + 1]} * t[q];
+    v[base + 2 * q] = y.x; v[base + 2 * q + 1] = y.y;
+  }
+}
+
 static __device__ __forceinline__ float quick_gelu_grad(float x) {
   // d/dx [x * s(1.702 x)] = s * (1 + 1.702 x (1 - s))
   const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));

@@ -1278,7 +1278,7 @@ void gemm256_kernel(const GemmParams p) {
               }
             }
 #pragma unroll
-            for (int e = 0; e < 16; e += 2) quick_gelu2(v[e], v[e + 1]);
+            for (int e = 0; e < 16; e += 8) quick_gelu8(v, e);
           } else {
             const unsigned short* axp = p.aux + orow * p.ldo + nb0;
             const uint4 a0 = *reinterpret_cast<const uint4*>(axp), a1 = *reinterpret_cast<const uint4*>(axp + 8);
