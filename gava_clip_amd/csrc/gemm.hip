@@ -1236,6 +1236,17 @@ void gemm256_kernel(const GemmParams p) {
       a_r += pairs_base(j);
       asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r_cur) : "v"(a_r) : "memory");
     }
+    const long row0_ = (long)(m0 + wr * 128 + fr_e);
+    // (pinned here: left to itself hipcc sinks the multiplies back into each row group's `m < M` branch)
+    auto pinned = [](long x) {
+      if (L8) return x;        // (the 8-bit kernels sit at the register limit: two more live registers there are spilled)
+      unsigned lo = (unsigned)x, hi = (unsigned)((unsigned long)x >> 32);
+      asm volatile("" : "+v"(lo), "+v"(hi));
+      return (long)(((unsigned long)hi << 32) | lo);
+    };
+    const long row0_o = pinned(row0_ * p.ldo);
+    const long row0_x16 = (EPI == GAVA_EPI_F32) ? pinned(row0_ * p.ldx16) : 0;
+    const long row0_o8 = L8 ? pinned(row0_ * p.ldo8) : 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int m = m0 + wr * 128 + i * 16 + fr_e;
@@ -1250,6 +1261,12 @@ void gemm256_kernel(const GemmParams p) {
           posr = p.pos + (long)(1 + pp) * p.N + nb0;
           timr = p.time + (long)(frame % p.T) * p.N + nb0;
         }
+        // element offsets of this lane's output row: one 64-bit multiply per TILE (row group 0) + a uniform step per row group, instead of
+        // a quarter-rate v_mul_lo_u32 / v_mad_u64_u32 set per row group and output array (51 of them per tile in the fc1 kernel)
+        const long off_o = EPI == GAVA_EPI_F32_PATCH ? orow * p.ldo : row0_o + (long)(i * 16) * p.ldo;
+        const long off_x16 = row0_x16 + (long)(i * 16) * p.ldx16;
+        const long off_o8 = L8 ? row0_o8 + (long)(i * 16) * p.ldo8 : 0;
+        (void)off_x16; (void)off_o8;
         float v[16];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -1269,7 +1286,7 @@ void gemm256_kernel(const GemmParams p) {
             }
           } else if (EPI == GAVA_EPI_H16_QGELU) {
             if (p.aux_out) {
-              unsigned short* ao = p.aux_out + orow * p.ldo + nb0;
+              unsigned short* ao = p.aux_out + off_o + nb0;
 #pragma unroll
               for (int hh = 0; hh < 2; ++hh) {
                 const uint2 x = pack4<P>(v[8 * hh], v[8 * hh + 1], v[8 * hh + 2], v[8 * hh + 3]);
@@ -1280,7 +1297,7 @@ void gemm256_kernel(const GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; e += 8) quick_gelu8(v, e);
           } else {
-            const unsigned short* axp = p.aux + orow * p.ldo + nb0;
+            const unsigned short* axp = p.aux + off_o + nb0;
             const uint4 a0 = *reinterpret_cast<const uint4*>(axp), a1 = *reinterpret_cast<const uint4*>(axp + 8);
             const unsigned aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
@@ -1289,7 +1306,7 @@ void gemm256_kernel(const GemmParams p) {
               v[2 * e + 1] *= quick_gelu_grad(aux_up((unsigned short)(aw[e] >> 16), p.aux_f16));
             }
           }
-          unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + orow * p.ldo + nb0;
+          unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + off_o + nb0;
           if (SPLIT) {
             uint2 hi[4], lo[4];
 #pragma unroll
@@ -1310,7 +1327,7 @@ void gemm256_kernel(const GemmParams p) {
                 r8[q] = __builtin_amdgcn_cvt_pk_bf8_f32(v[4 * q], v[4 * q + 1], 0u, false);
                 r8[q] = __builtin_amdgcn_cvt_pk_bf8_f32(v[4 * q + 2], v[4 * q + 3], r8[q], true);
               }
-              *reinterpret_cast<uint4*>(p.out8 + orow * p.ldo8 + nb0) = make_uint4(r8[0], r8[1], r8[2], r8[3]);
+              *reinterpret_cast<uint4*>(p.out8 + off_o8 + nb0) = make_uint4(r8[0], r8[1], r8[2], r8[3]);
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1329,8 +1346,8 @@ void gemm256_kernel(const GemmParams p) {
           }
         } else if (HL) {
           // the stream leaves as the pair: hi = h16(v), the operand of the GEMM that consumes the fold, and lo = fp16(v - hi)
-          unsigned short* ho = p.x16 + orow * p.ldx16 + nb0;
-          unsigned short* lp = p.xlo + orow * p.ldx16 + nb0;
+          unsigned short* ho = p.x16 + off_x16 + nb0;
+          unsigned short* lp = p.xlo + off_x16 + nb0;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             uint2 ha, la, hb, lb;
@@ -1347,7 +1364,7 @@ void gemm256_kernel(const GemmParams p) {
             if (fg == 0) *reinterpret_cast<float2*>(smem + PS_OFF + ((wr * 128 + i * 16 + fr) * 4 + wc) * 8) = make_float2(ps1, ps2);
           } else if (fg == 0) p.rowsum[orow * (p.N / 64) + (n0 + wc * 64) / 64] = make_float2(ps1, ps2);
         } else {
-          float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + nb0;
+          float* o = reinterpret_cast<float*>(p.out) + off_o + nb0;
           if (EPI == GAVA_EPI_F32_PATCH) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -1361,7 +1378,7 @@ void gemm256_kernel(const GemmParams p) {
             *reinterpret_cast<float4*>(o + CJ * jj) = make_float4(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
           if (EPI == GAVA_EPI_F32 && p.x16) {
             // producer side of the LayerNorm folding: 16-bit copy of the row segment + its (sum x, sum x^2)
-            unsigned short* xo = p.x16 + orow * p.ldx16 + nb0;
+            unsigned short* xo = p.x16 + off_x16 + nb0;
             float ps1 = 0.f, ps2 = 0.f;
             (void)xo;
             if (X16_STAGE) {
