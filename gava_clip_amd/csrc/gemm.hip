@@ -1247,6 +1247,7 @@ void gemm256_kernel(const GemmParams p) {
     const long row0_o = pinned(row0_ * p.ldo);
     const long row0_x16 = (EPI == GAVA_EPI_F32) ? pinned(row0_ * p.ldx16) : 0;
     const long row0_o8 = L8 ? pinned(row0_ * p.ldo8) : 0;
+    const long res_next = HL ? pinned((long)(m0n + wr * 128 + fr_e) * p.ldr) : 0;      // (m0n: meaningful when there is a next tile)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int m = m0 + wr * 128 + i * 16 + fr_e;
@@ -1420,7 +1421,18 @@ void gemm256_kernel(const GemmParams p) {
       }
       // next tile: its residual rows go straight into the accumulators just freed (all 32 loads in flight
       // together, no temporaries, no wait inside the epilogue)
-      if (ACC_RES && j + 1 < my_tiles) {
+      if (HL && j + 1 < my_tiles) {
+        // (the pair of the next tile, addressed like the stores above: one row-offset multiply per tile - res_next - a uniform step per row
+        // group, rows past M clamped by a 64-bit min against the last row's offset)
+        long ro = res_next + (long)(i * 16) * p.ldr;
+        const long rmax = (long)(p.M - 1) * p.ldr;
+        ro = ro < rmax ? ro : rmax;
+        const long off = ro + n0n + wc * 64 + 8 * fg_e;
+        acc[i][0] = *reinterpret_cast<const f32x4_t*>(p.r16 + off);
+        acc[i][1] = *reinterpret_cast<const f32x4_t*>(p.r16 + off + 32);
+        acc[i][2] = *reinterpret_cast<const f32x4_t*>(p.rlo + off);
+        acc[i][3] = *reinterpret_cast<const f32x4_t*>(p.rlo + off + 32);
+      } else if (ACC_RES && j + 1 < my_tiles) {
         load_resid(i, m0n, n0n);
       } else if (!CAN_FOLD) {
 #pragma unroll
