@@ -1282,8 +1282,12 @@ void gemm256_kernel(const GemmParams p) {
         if (EPI == GAVA_EPI_H16 || EPI == GAVA_EPI_H16_QGELU || EPI == GAVA_EPI_H16_QGELU_BWD) {
           if (EPI == GAVA_EPI_H16) {
             if (nb0 < p.scale_cols) {
+              // (the factor in a VECTOR register: as a scalar operand hipcc made eight copies of the {scale, scale} pair for its eight
+              // packed multiplies, spilled them, and read each back with two v_readlane + s_nop - 144 v_readlane per tile)
+              float sc;
+              asm volatile("v_mov_b32 %0, %1" : "=v"(sc) : "s"(p.scale));
 #pragma unroll
-              for (int e = 0; e < 16; ++e) v[e] *= p.scale;
+              for (int e = 0; e < 16; ++e) v[e] *= sc;
             }
           } else if (EPI == GAVA_EPI_H16_QGELU) {
             if (p.aux_out) {
